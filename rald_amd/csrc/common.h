@@ -1,0 +1,66 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels.  wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+namespace rald {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;   // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;     // 16x16 MFMA accumulator
+typedef __attribute__((ext_vector_type(16))) float f32x16;   // 32x32 MFMA accumulator
+
+constexpr int WAVE = 64;
+
+// ---- error plumbing: C-ABI functions return int status + rald_last_error() ------------
+void set_error(const std::string& msg);
+#define RALD_CHECK(cond, msg)                                                       \
+    do {                                                                            \
+        if (!(cond)) {                                                              \
+            ::rald::set_error(std::string(__FILE__) + ":" + std::to_string(__LINE__) + ": " + (msg)); \
+            return 1;                                                               \
+        }                                                                           \
+    } while (0)
+#define RALD_HIP(expr)                                                              \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess) {                                                     \
+            ::rald::set_error(std::string(__FILE__) + ":" + std::to_string(__LINE__) + ": " #expr " -> " + hipGetErrorString(_e)); \
+            return 2;                                                               \
+        }                                                                           \
+    } while (0)
+#define RALD_TRY(expr)                                                              \
+    do {                                                                            \
+        int _rc = (expr);                                                           \
+        if (_rc) return _rc;                                                        \
+    } while (0)
+
+// ---- device helpers --------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float gelu_erf(float x) {   // exact erf GELU (F.gelu default)
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
+    bf16x4 r;
+    r[0] = (bf16)a; r[1] = (bf16)b; r[2] = (bf16)c; r[3] = (bf16)d;
+    return r;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+}  // namespace rald

@@ -1,0 +1,66 @@
+// Internal launch interface of the kernel files (not part of the C-ABI; include/rald_hip.h is).
+#pragma once
+#include "common.h"
+
+namespace rald {
+
+// ---------------------------------------------------------------- gemm.hip
+enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_RESID = 2, EPI_GEGLU = 3 };
+struct GemmArgs {
+    const bf16* A; int64_t lda; int64_t strideA;   // [batch][M][K] activations (K contiguous)
+    const bf16* B; int64_t ldb; int64_t strideB;   // [batch][N][K] weights     (K contiguous)
+    void* C;       int64_t ldc; int64_t strideC;   // bf16 or f32, see epilogue
+    const float* bias;                             // [N] or nullptr
+    int M, N, K, batch;
+    float alpha;
+};
+int gemm_nt(const GemmArgs& a, int epi, hipStream_t st);
+inline GemmArgs gemm_args(const bf16* A, int64_t lda, const bf16* B, int64_t ldb, void* C, int64_t ldc,
+                          const float* bias, int M, int N, int K) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.strideA = 0; g.B = B; g.ldb = ldb; g.strideB = 0;
+    g.C = C; g.ldc = ldc; g.strideC = 0; g.bias = bias; g.M = M; g.N = N; g.K = K; g.batch = 1; g.alpha = 1.f;
+    return g;
+}
+
+// ---------------------------------------------------------------- norm.hip
+// out_bf16[m][c] = LN(x[m])[c] * (add_one + g[s][c]) + b[s][c],  s = (m / rows_per_group) * gstride
+int layernorm_mod(const float* x, bf16* out, int M, int D, const float* g, const float* b,
+                  int64_t gstride, int rows_per_group, float add_one, float eps, hipStream_t st);
+// x_f32[m][n] = coef[s].c_in * sum_k xin[m][k] * W[n][k]      (proj_in fused with EDM c_in)
+int proj_in(const float* xin, const float* W, float* x, int M, int C, int D, const float* coef,
+            int coef_stride, int rows_per_group, hipStream_t st);
+// D_x[m][c] = c_skip * xin[m][c] + c_out * sum_k LN_affine(x[m])[k] * Wout[c][k]
+int final_norm_proj(const float* x, const float* gamma, const float* beta, const float* Wout,
+                    const float* xin, float* out, int M, int D, int C, const float* coef,
+                    int coef_stride, int rows_per_group, hipStream_t st);
+
+// ---------------------------------------------------------------- attention.hip
+struct AttnArgs {
+    const bf16* Q;  int64_t ldq,  strideQ;     // Q [b][i][h*64+d]
+    const bf16* K;  int64_t ldk,  strideK;     // K [b][j][h*64+d]
+    const bf16* Vt; int64_t ldvt, strideVt;    // Vt[b][h*64+d][j]  (keys contiguous, zero padded to 32)
+    bf16* O;        int64_t ldo,  strideO;     // O [b][i][h*64+d]
+    int nq, nk, heads, batch;
+    float scale;
+};
+int attention_d64(const AttnArgs& a, hipStream_t st);
+
+// ---------------------------------------------------------------- small.hip
+enum { ACT_NONE = 0, ACT_SILU = 1 };
+// out[s][n] = act(sum_k in[s][k] * W[n][k] + bias[n]); fp32 throughout, S small (t-embed path)
+int skinny_linear(const float* in, const float* W, const float* bias, float* out, int S, int N, int K,
+                  int act, hipStream_t st);
+// pe[s][0:128] = cos(c_noise[s]*f_i), pe[s][128:256] = sin(..)   (PositionalEmbedding)
+int positional_embedding(const float* c_noise, float* pe, int S, int channels, hipStream_t st);
+int cast_f32_bf16(const float* in, bf16* out, int64_t n, hipStream_t st);
+// dst_bf16[map(r)][c] = src_f32[r][c] ; map==nullptr -> identity; ld_dst >= cols (pad zero-filled by caller)
+int pack_rows_bf16(const float* src, bf16* dst, int rows, int cols, int64_t ld_dst, const int* rowmap, hipStream_t st);
+int scale_f32(const float* in, float* out, float s, int64_t n, hipStream_t st);
+// Heun/Euler updates of edm_sampler (models_radar_generation.py:265-273)
+int heun_euler(const float* x_hat, const float* denoised, float t_hat, float t_next, float* d_cur,
+               float* x_next, int64_t n, hipStream_t st);
+int heun_correct(const float* x_hat, const float* x_euler, const float* denoised, const float* d_cur,
+                 float t_hat, float t_next, float* x_next, int64_t n, hipStream_t st);
+
+}  // namespace rald

@@ -1,0 +1,135 @@
+"""Pin the CPU oracle (oracle/rald_oracle.py) against the golden vectors captured from the
+reference's own model code (tests/golden/make_golden.py).  CPU only, fp32: rel-L2 <= 1e-5
+(SURVEY.md §8d 'fp32 kernels vs oracle')."""
+import json
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden, rel_l2
+from oracle import rald_oracle as O
+from rald_amd import synth, weights
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def sd_d2():
+    return weights.make_state_dict(weights.dit_spec(depth=2), seed=0)
+
+
+@pytest.fixture(scope="module")
+def sd_dit():
+    return weights.make_state_dict(weights.dit_spec(depth=24), seed=0)
+
+
+def test_specs_match_reference_state_dict_keys():
+    keys = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))
+    as_list = lambda spec: [[n, list(s)] for n, s in spec]
+    assert as_list(weights.dit_spec(depth=24)) == keys["dit"]
+    assert as_list(weights.ae_spec()) == keys["ae"]
+    assert as_list(weights.ae_spec(dim=256, num_latents=128)) == keys["ae_tiny"]
+
+
+def test_g1_ops(sd_d2):
+    g = load_golden("g1_ops.npz")
+    x = synth.normal([2, 32, 512], 11)
+    ctx = synth.cond_tokens(2, 64, 512, seed=12)
+    pe = O.positional_embedding(torch.tensor([0.3]))
+    assert rel_l2(pe, g["pos_emb"]) < TOL
+    t_emb = O.timestep_embed(sd_d2, torch.tensor([0.3]))
+    assert rel_l2(t_emb, g["t_emb"]) < TOL
+    p = "model.transformer_blocks.0."
+    assert rel_l2(O.ada_layer_norm(sd_d2, p + "norm1", x, t_emb), g["adaln"]) < TOL
+    assert rel_l2(O.cross_attention(sd_d2, p + "attn1", x), g["self_attn"]) < TOL
+    assert rel_l2(O.cross_attention(sd_d2, p + "attn2", x, ctx), g["cross_attn"]) < TOL
+    assert rel_l2(O.geglu_ff(sd_d2, p + "ff.net.0.proj", p + "ff.net.2", x), g["ff"]) < TOL
+    assert rel_l2(O.transformer_block(sd_d2, p, x, t_emb, ctx), g["block"]) < TOL
+
+
+def test_g1_depth2_precond_and_100step_sampler(sd_d2):
+    g = load_golden("g1_depth2.npz")
+    cube = synth.radar_cube(2)
+    cond = O.process_radar_cond(sd_d2, cube)
+    assert rel_l2(cond, g["cond"]) < TOL
+    x = synth.latents([0, 1])
+    sig = torch.tensor([1.5, 0.05]).reshape(2, 1, 1)
+    assert rel_l2(O.edm_precond(sd_d2, x, sig, cond, depth=2), g["d_x"]) < TOL
+    s = O.edm_sampler(lambda xx, ss: O.edm_precond(sd_d2, xx, ss, cond, depth=2),
+                      synth.latents([0, 1]), num_steps=100)
+    assert rel_l2(s, g["sample100"]) < 1e-4     # 199 compounding fp32 NFEs
+
+
+def test_g2_transformer(sd_dit):
+    g = load_golden("g2_transformer.npz")
+    x = synth.latents([0, 1])
+    t = torch.tensor([0.25, -1.0])
+    out = O.latent_transformer(sd_dit, x, t, synth.cond_tokens(2), depth=24)
+    assert rel_l2(out, g["out"]) < TOL
+
+
+def test_g2_transformer_context_dim_1024():
+    sd = weights.make_state_dict(weights.dit_spec(depth=24, context_dim=1024, with_radar=False,
+                                                  prefix=""), seed=0)
+    g = load_golden("g2_transformer_ctx1024.npz")
+    out = O.latent_transformer(sd, synth.latents([0, 1]), torch.tensor([0.25, -1.0]),
+                               synth.cond_tokens(2, 64, 1024, seed=778), depth=24, prefix="")
+    assert rel_l2(out, g["out"]) < TOL
+
+
+def test_g7_radar_encoder_and_g3_precond(sd_dit):
+    g7 = load_golden("g7_radar_encoder.npz")
+    g3 = load_golden("g3_precond.npz")
+    cube = synth.radar_cube(2)
+    taps = {}
+    z = O.radar_encoder(sd_dit, cube[..., 0:1].permute(0, 4, 1, 2, 3), taps=taps)
+    assert rel_l2(z, g7["z"]) < TOL
+    for name, (mean, amax) in zip(g7["stage_names"], g7["stage_stats"]):
+        h = taps[str(name)]
+        assert abs(h.mean().item() - mean) < 1e-5 + 1e-4 * abs(mean)
+        assert abs(h.abs().max().item() - amax) < 1e-4 * amax
+    tokens = O.process_radar_cond(sd_dit, cube)
+    assert rel_l2(tokens, g3["cond_tokens"]) < TOL
+    x = synth.latents([0, 1])
+    for s in (80.0, 1.0, 0.002):
+        d = O.edm_precond(sd_dit, x * max(s, 1.0), torch.tensor(s), tokens, depth=24)
+        assert rel_l2(d, g3[f"d_sigma_{s}"]) < TOL
+
+
+@pytest.mark.slow
+def test_g4_sample18_as_shipped(sd_dit):
+    """EDMPrecond.sample, B=2, seeds {0,1}, 18 Heun steps (35 NFE) - the reference run
+    re-encodes the radar cube inside every NFE; the oracle hoists it (bit-identical)."""
+    g = load_golden("g4_sample18.npz")
+    s = O.dit_sample(sd_dit, synth.radar_cube(2), synth.latents([0, 1]), depth=24)
+    assert rel_l2(s, g["sample"]) < 1e-4
+
+
+def test_g5_autoencoder():
+    sd = weights.make_state_dict(weights.ae_spec(), seed=0)
+    g = load_golden("g5_ae.npz")
+    pc = synth.point_cloud(2, 10000)
+    kl, z, mean, logvar = O.ae_encode(sd, pc, g["eps"])
+    assert rel_l2(mean, g["mean"]) < TOL and rel_l2(logvar, g["logvar"]) < TOL
+    assert rel_l2(z, g["z"]) < TOL and rel_l2(kl, g["kl"]) < TOL
+    logits = O.ae_decode(sd, g["z"], synth.queries(2, 4096), depth=24)
+    assert rel_l2(logits, g["logits"]) < TOL
+
+
+def test_g5_tiny_autoencoder():
+    """BASELINE config #1: create_autoencoder(dim=256, M=128, N=1000, 'mix'), B=2, CPU."""
+    sd = weights.make_state_dict(weights.ae_spec(dim=256, num_latents=128), seed=0)
+    g = load_golden("g5_ae_tiny.npz")
+    kl, z, _, _ = O.ae_encode(sd, synth.point_cloud(2, 1000), g["eps"])
+    logits = O.ae_decode(sd, z, synth.queries(2, 1000), depth=24).squeeze(-1)
+    assert rel_l2(kl, g["kl"]) < TOL
+    assert rel_l2(logits, g["logits"]) < TOL
+
+
+def test_g6_edm_loss(sd_d2):
+    g = load_golden("g6_edmloss.npz")
+    cond = O.process_radar_cond(sd_d2, synth.radar_cube(2))
+    y = synth.normal([2, 512, 32], 21)
+    loss = O.edm_loss(sd_d2, y, cond, g["rnd_normal"], g["noise"], depth=2)
+    assert abs(loss.item() - g["loss"].item()) < 1e-5 * abs(g["loss"].item())
