@@ -1,0 +1,111 @@
+/* rald_hip.h - C-ABI of librald_hip.so: the MI355X (gfx950) implementation of RaLD's hot path.
+ *
+ * The reference (RoyAPTX4869/RaLD) has no FFI of its own: its seam is the Python nn.Module API
+ * (SURVEY.md 8b).  These entry points are what a binding for that seam calls; each one names
+ * the reference interface (file:line under the reference root) it replaces.  INTEGRATION.md
+ * shows the ctypes stub a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; rald_last_error() gives the
+ *     message for the calling thread.  Nothing is printed, nothing aborts.
+ *   - all tensor pointers are DEVICE pointers (hipMalloc'd or torch-allocated), dense,
+ *     row-major, fp32 unless stated; `stream` is a hipStream_t (NULL = default stream).
+ *     Work is enqueued on `stream`; no entry point synchronises except *_create / *_destroy /
+ *     *_load_weight / *_finalize / *_reserve (setup-time, blocking).
+ *   - handles are re-entrant per handle (one stream at a time per handle); no global state.
+ *   - weights are loaded by their reference checkpoint key (utils/misc.py:309-316), fp32,
+ *     from host OR device memory; packing to the kernels' layouts (bf16, fused/permuted rows)
+ *     happens inside the library.
+ */
+#ifndef RALD_HIP_H
+#define RALD_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* rald_last_error(void);
+int rald_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Denoiser: EDMPrecond + LatentArrayTransformer  (model/models_radar_generation.py:171-233,
+ * :314-449)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct rald_dit rald_dit;
+
+typedef struct rald_dit_config {
+    int32_t n_latents;      /* 512  (EDMPrecond n_latents, :316)                        */
+    int32_t channels;       /* 32   latent channels C (:317)                            */
+    int32_t depth;          /* 24   transformer blocks (:324, factories :452-482)       */
+    int32_t n_heads;        /* 8                                                        */
+    int32_t d_head;         /* 64   (only 64 is implemented)                            */
+    int32_t t_channels;     /* 256  PositionalEmbedding width (:336)                    */
+    int32_t context_dim;    /* 512  width of the condition tokens (:180-193)            */
+    int32_t n_cond_tokens;  /* 64   = 8*4*2 radar tokens (:405)                         */
+    int32_t with_radar_enc; /* 1: radar_enc.* / radar_*_emb / radar_token_project loaded */
+    int32_t enc_hidden_ch;  /* 64   (configs.enc_hidden_ch, :348)                       */
+    int32_t enc_radar_ch;   /* 16   (configs.enc_radar_ch, :349)                        */
+    int32_t radar_r, radar_a, radar_e; /* 128, 64, 32 input cube (R,A,E)                */
+    float sigma_data;       /* 1.0 (:321)                                               */
+} rald_dit_config;
+
+void rald_dit_default_config(rald_dit_config* cfg);
+int rald_dit_create(const rald_dit_config* cfg, rald_dit** out);
+void rald_dit_destroy(rald_dit* h);
+/* One tensor of the reference state_dict, by key (e.g. "model.transformer_blocks.3.attn1.to_q.weight");
+ * `data` = fp32, host or device, `nelem` elements.  Unknown keys and wrong sizes are errors. */
+int rald_dit_load_weight(rald_dit* h, const char* name, const float* data, int64_t nelem);
+/* Checks that every key was loaded (strict=True semantics, utils/misc.py:346). */
+int rald_dit_finalize(rald_dit* h);
+/* Pre-allocates activation workspace for batches up to max_batch (otherwise grown on demand). */
+int rald_dit_reserve(rald_dit* h, int32_t max_batch);
+
+/* Noise-level table: for each of the n sigmas (HOST array) computes the EDM coefficients
+ * (c_in, c_skip, c_out, c_noise; :422-425), the timestep embedding (:217-219) and all
+ * depth*3 AdaLayerNorm modulations (:128-129) once; rald_dit_denoise refers to rows of it. */
+int rald_dit_set_sigmas(rald_dit* h, const float* sigmas_host, int32_t n, void* stream);
+
+/* Bytes of the per-batch condition cache (K and V^T of the condition tokens for every block). */
+int64_t rald_dit_cond_cache_bytes(const rald_dit* h, int32_t batch);
+/* Condition tokens [B, n_cond_tokens, context_dim] -> cond cache (the K/V projections of
+ * attn2 are step-invariant; CrossAttention.to_k/to_v :63-64). */
+int rald_dit_encode_cond_tokens(rald_dit* h, const float* tokens, int32_t batch, void* cond_cache, void* stream);
+/* EDMPrecond.process_radar_cond (:363-407): cube [B,R,A,E,2] -> tokens [B,64,C] (optional
+ * output, may be NULL) and the cond cache.  Run ONCE per sample, outside the sampling loop. */
+int rald_dit_encode_cond(rald_dit* h, const float* cube, int32_t batch, float* out_tokens, void* cond_cache, void* stream);
+
+/* One NFE = EDMPrecond.forward (:412-430) with the condition already encoded:
+ *   D_x = c_skip*x + c_out*F(c_in*x, c_noise, cond).   x,out: [B, n_latents, channels].
+ * sigma_row selects the row of the table set by rald_dit_set_sigmas; per_sample != 0 means
+ * sample b uses row sigma_row+b (training-style [B,1,1] sigmas, :419).
+ * raw_F != 0 returns F(x, c_noise, cond) with no pre/post-conditioning
+ * (= LatentArrayTransformer.forward, :215-233, c_noise = ln(sigma)/4 of the table row). */
+int rald_dit_denoise(rald_dit* h, const float* x, int32_t batch, int32_t sigma_row, int32_t per_sample,
+                     const void* cond_cache, float* out, int32_t raw_F, void* stream);
+
+/* edm_sampler (:235-275) at S_churn=0: latents [B,n_latents,channels] ~ N(0,1) -> samples.
+ * 2*num_steps-1 NFEs.  The sigma table is (re)built internally for the schedule. */
+int rald_dit_sample(rald_dit* h, const float* latents, int32_t batch, const void* cond_cache, int32_t num_steps,
+                    float sigma_min, float sigma_max, float rho, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Kernel-level entry points (what the parity tests and microbenchmarks drive directly)
+ * ---------------------------------------------------------------------------------------- */
+/* C[b][m][n] = alpha * sum_k A[b][m][k]*B[b][n][k] (+bias[n]); A,B bf16 (K contiguous).
+ * epilogue: 0 bf16 out, 1 f32 out, 2 f32 C += result, 3 GEGLU (packed B rows, bf16 out, N/2 cols) */
+int rald_op_gemm_nt(const void* A, int64_t lda, int64_t strideA, const void* B, int64_t ldb, int64_t strideB,
+                    void* C, int64_t ldc, int64_t strideC, const float* bias, int32_t M, int32_t N, int32_t K,
+                    int32_t batch, float alpha, int32_t epilogue, void* stream);
+/* out_bf16 = LayerNorm(x_f32[M][D]) * (add_one + g[row/rows_per_group*gstride + c]) + b[...] */
+int rald_op_layernorm(const float* x, void* out_bf16, int32_t M, int32_t D, const float* g, const float* b,
+                      int64_t gstride, int32_t rows_per_group, float add_one, float eps, void* stream);
+/* multi-head attention, head dim 64; Q[b][i][h*64+d], K[b][j][h*64+d], Vt[b][h*64+d][j] bf16 */
+int rald_op_attention(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK,
+                      const void* Vt, int64_t ldvt, int64_t strideVt, void* O, int64_t ldo, int64_t strideO,
+                      int32_t nq, int32_t nk, int32_t k_rows, int32_t heads, int32_t batch, float scale, void* stream);
+int rald_op_cast_bf16(const float* in, void* out_bf16, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RALD_HIP_H */

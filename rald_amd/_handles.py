@@ -1,0 +1,147 @@
+"""Python owners of the C handles: device-memory plumbing (torch tensors -> raw pointers, the
+current torch stream -> hipStream_t) around librald_hip.so.  No arithmetic happens here."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import DitConfig, check, lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: torch.Tensor) -> int:
+    return t.data_ptr()
+
+
+def _need_cuda(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"rald_amd: {what} must live on the GPU (cuda tensor); this package has no CPU path")
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+class DitHandle:
+    """rald_dit* + its condition cache.  One handle per module per device."""
+
+    def __init__(self, cfg: DitConfig):
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        check(lib().rald_dit_create(C.byref(cfg), C.byref(self._h)))
+        self._cache: Optional[torch.Tensor] = None
+        self._cache_batch = 0
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().rald_dit_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def load(self, named: Iterable[Tuple[str, torch.Tensor]]) -> None:
+        for name, t in named:
+            t = _f32c(t)                       # host or device fp32; the library stages either
+            check(lib().rald_dit_load_weight(self._h, name.encode(), C.c_void_p(_ptr(t)), t.numel()))
+        check(lib().rald_dit_finalize(self._h))
+
+    def set_sigmas(self, sigmas) -> None:
+        s = [float(v) for v in sigmas]
+        arr = (C.c_float * len(s))(*s)
+        check(lib().rald_dit_set_sigmas(self._h, arr, len(s), C.c_void_p(_stream())))
+
+    def new_cache(self, batch: int, device) -> torch.Tensor:
+        nbytes = lib().rald_dit_cond_cache_bytes(self._h, batch)
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+    def encode_cond_tokens(self, tokens: torch.Tensor) -> torch.Tensor:
+        _need_cuda(tokens, "condition tokens")
+        tokens = _f32c(tokens)
+        B, T, Cd = tokens.shape
+        if T != self.cfg.n_cond_tokens or Cd != self.cfg.context_dim:
+            raise RuntimeError(f"condition tokens must be [B,{self.cfg.n_cond_tokens},{self.cfg.context_dim}], got {tuple(tokens.shape)}")
+        cache = self.new_cache(B, tokens.device)
+        check(lib().rald_dit_encode_cond_tokens(self._h, C.c_void_p(_ptr(tokens)), B, C.c_void_p(_ptr(cache)), C.c_void_p(_stream())))
+        return cache
+
+    def encode_cond(self, cube: torch.Tensor, want_tokens: bool = True):
+        _need_cuda(cube, "radar cube")
+        cube = _f32c(cube)
+        B = cube.shape[0]
+        cache = self.new_cache(B, cube.device)
+        tokens = None
+        tp = C.c_void_p(0)
+        if want_tokens:
+            tokens = torch.empty(B, self.cfg.n_cond_tokens, self.cfg.n_heads * self.cfg.d_head, device=cube.device, dtype=torch.float32)
+            tp = C.c_void_p(_ptr(tokens))
+        check(lib().rald_dit_encode_cond(self._h, C.c_void_p(_ptr(cube)), B, tp, C.c_void_p(_ptr(cache)), C.c_void_p(_stream())))
+        return tokens, cache
+
+    def denoise(self, x: torch.Tensor, cache: torch.Tensor, sigma_row: int = 0, per_sample: bool = False,
+                raw_F: bool = False) -> torch.Tensor:
+        _need_cuda(x, "x")
+        x = _f32c(x)
+        out = torch.empty_like(x)
+        check(lib().rald_dit_denoise(self._h, C.c_void_p(_ptr(x)), x.shape[0], sigma_row, int(per_sample),
+                                     C.c_void_p(_ptr(cache)), C.c_void_p(_ptr(out)), int(raw_F), C.c_void_p(_stream())))
+        return out
+
+    def sample(self, latents: torch.Tensor, cache: torch.Tensor, num_steps: int = 18, sigma_min: float = 0.002,
+               sigma_max: float = 80.0, rho: float = 7.0) -> torch.Tensor:
+        _need_cuda(latents, "latents")
+        latents = _f32c(latents)
+        out = torch.empty_like(latents)
+        check(lib().rald_dit_sample(self._h, C.c_void_p(_ptr(latents)), latents.shape[0], C.c_void_p(_ptr(cache)), num_steps,
+                                    sigma_min, sigma_max, rho, C.c_void_p(_ptr(out)), C.c_void_p(_stream())))
+        return out
+
+
+# ---- kernel-level wrappers used by the parity tests and microbenchmarks -----------------------
+def op_gemm_nt(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = 0,
+               C_inout: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
+    """A [batch?,M,K] bf16, B [batch?,N,K] bf16 -> C.  epilogue 0 bf16, 1 f32, 2 f32 accumulate into
+    C_inout, 3 GEGLU (B rows / bias pre-packed)."""
+    batched = A.dim() == 3 or B.dim() == 3
+    batch = (A.shape[0] if A.dim() == 3 else B.shape[0]) if batched else 1
+    M, K = A.shape[-2], A.shape[-1]
+    N = B.shape[-2]
+    sA = A.stride(0) if A.dim() == 3 else 0
+    sB = B.stride(0) if B.dim() == 3 else 0
+    nc = N // 2 if epilogue == 3 else N
+    if epilogue == 2:
+        out = C_inout
+    else:
+        shape = (batch, M, nc) if batched else (M, nc)
+        out = torch.empty(shape, device=A.device, dtype=torch.bfloat16 if epilogue in (0, 3) else torch.float32)
+    sC = out.stride(0) if out.dim() == 3 else 0
+    check(lib().rald_op_gemm_nt(C.c_void_p(_ptr(A)), A.stride(-2), sA, C.c_void_p(_ptr(B)), B.stride(-2), sB,
+                                C.c_void_p(_ptr(out)), out.stride(-2), sC,
+                                C.c_void_p(_ptr(bias) if bias is not None else 0), M, N, K, batch, alpha, epilogue,
+                                C.c_void_p(_stream())))
+    return out
+
+
+def op_layernorm(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, gstride: int = 0, rows_per_group: int = 1,
+                 add_one: float = 0.0, eps: float = 1e-5) -> torch.Tensor:
+    M, D = x.shape
+    out = torch.empty(M, D, device=x.device, dtype=torch.bfloat16)
+    check(lib().rald_op_layernorm(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(out)), M, D, C.c_void_p(_ptr(g)), C.c_void_p(_ptr(b)),
+                                  gstride, rows_per_group, add_one, eps, C.c_void_p(_stream())))
+    return out
+
+
+def op_attention(Q: torch.Tensor, K: torch.Tensor, Vt: torch.Tensor, nk: int, heads: int, scale: float) -> torch.Tensor:
+    """Q [B,nq,H*64], K [B,k_rows,H*64], Vt [B,H*64,ldvt] (bf16) -> O [B,nq,H*64] bf16."""
+    Bn, nq, HD = Q.shape
+    O = torch.empty(Bn, nq, HD, device=Q.device, dtype=torch.bfloat16)
+    check(lib().rald_op_attention(C.c_void_p(_ptr(Q)), Q.stride(1), Q.stride(0), C.c_void_p(_ptr(K)), K.stride(1), K.stride(0),
+                                  C.c_void_p(_ptr(Vt)), Vt.stride(1), Vt.stride(0), C.c_void_p(_ptr(O)), O.stride(1), O.stride(0),
+                                  nq, nk, K.shape[1], heads, Bn, scale, C.c_void_p(_stream())))
+    return O

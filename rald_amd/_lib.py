@@ -1,0 +1,92 @@
+"""ctypes binding of librald_hip.so (include/rald_hip.h).
+
+The library is the product: if it is missing or fails to load, every entry point raises -
+there is no eager/PyTorch fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librald_hip.so")
+_lock = threading.Lock()
+_lib = None
+
+c_void_p, c_int, c_i64, c_float, c_char_p = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_char_p
+c_float_p = C.POINTER(C.c_float)
+
+
+class DitConfig(C.Structure):
+    _fields_ = [("n_latents", c_int), ("channels", c_int), ("depth", c_int), ("n_heads", c_int),
+                ("d_head", c_int), ("t_channels", c_int), ("context_dim", c_int),
+                ("n_cond_tokens", c_int), ("with_radar_enc", c_int), ("enc_hidden_ch", c_int),
+                ("enc_radar_ch", c_int), ("radar_r", c_int), ("radar_a", c_int), ("radar_e", c_int),
+                ("sigma_data", c_float)]
+
+
+class AeConfig(C.Structure):
+    _fields_ = [("dim", c_int), ("num_latents", c_int), ("latent_dim", c_int), ("depth", c_int),
+                ("heads", c_int), ("dim_head", c_int), ("num_inputs", c_int)]
+
+
+# name -> (restype, argtypes); everything include/rald_hip.h declares
+SIGNATURES = {
+    "rald_last_error": (c_char_p, []),
+    "rald_version": (c_int, []),
+    "rald_dit_default_config": (None, [C.POINTER(DitConfig)]),
+    "rald_dit_create": (c_int, [C.POINTER(DitConfig), C.POINTER(c_void_p)]),
+    "rald_dit_destroy": (None, [c_void_p]),
+    "rald_dit_load_weight": (c_int, [c_void_p, c_char_p, c_void_p, c_i64]),
+    "rald_dit_finalize": (c_int, [c_void_p]),
+    "rald_dit_reserve": (c_int, [c_void_p, c_int]),
+    "rald_dit_set_sigmas": (c_int, [c_void_p, c_float_p, c_int, c_void_p]),
+    "rald_dit_cond_cache_bytes": (c_i64, [c_void_p, c_int]),
+    "rald_dit_encode_cond_tokens": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "rald_dit_encode_cond": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "rald_dit_denoise": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "rald_dit_sample": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_float, c_float, c_float, c_void_p, c_void_p]),
+    "rald_op_gemm_nt": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p,
+                                c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "rald_op_layernorm": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_i64, c_int, c_float, c_float, c_void_p]),
+    "rald_op_attention": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64,
+                                  c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "rald_op_cast_bf16": (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
+}
+
+
+def build_library(verbose: bool = False) -> str:
+    """Compile rald_amd/csrc/*.hip for gfx950 into rald_amd/librald_hip.so (hipcc cross-compiles
+    without a GPU).  Returns the library path."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j", str(min(8, os.cpu_count() or 1))]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or r.returncode:
+        print(r.stdout[-4000:], r.stderr[-8000:])
+    if r.returncode:
+        raise RuntimeError("building librald_hip.so failed")
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library (cached).  Raises if it is absent - never falls back."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                   "(or `make -C rald_amd/csrc`); rald_amd has no CPU/PyTorch fallback")
+            L = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(L, name)          # AttributeError if the symbol is not exported
+                fn.restype = res
+                fn.argtypes = args
+            _lib = L
+        return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = lib().rald_last_error()
+        raise RuntimeError(f"librald_hip: {msg.decode() if msg else 'error'} (status {rc})")

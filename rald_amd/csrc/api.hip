@@ -1,0 +1,95 @@
+// extern "C" surface of librald_hip.so (include/rald_hip.h).  Thin: argument checks + dispatch.
+#include "dit.h"
+
+using namespace rald;
+
+struct rald_dit { Dit impl; };
+
+extern "C" {
+
+const char* rald_last_error(void) { return rald::last_error(); }
+int rald_version(void) { return 1; }
+
+void rald_dit_default_config(rald_dit_config* c) {
+    c->n_latents = 512; c->channels = 32; c->depth = 24; c->n_heads = 8; c->d_head = 64; c->t_channels = 256;
+    c->context_dim = 512; c->n_cond_tokens = 64; c->with_radar_enc = 1; c->enc_hidden_ch = 64; c->enc_radar_ch = 16;
+    c->radar_r = 128; c->radar_a = 64; c->radar_e = 32; c->sigma_data = 1.0f;
+}
+int rald_dit_create(const rald_dit_config* cfg, rald_dit** out) {
+    RALD_CHECK(cfg && out, "rald_dit_create: null argument");
+    rald_dit* h = new rald_dit();
+    h->impl.cfg = *cfg;
+    int rc = h->impl.create();
+    if (rc) { delete h; return rc; }
+    *out = h;
+    return 0;
+}
+void rald_dit_destroy(rald_dit* h) {
+    if (!h) return;
+    (void)hipDeviceSynchronize();
+    delete h;
+}
+int rald_dit_load_weight(rald_dit* h, const char* name, const float* data, int64_t nelem) {
+    RALD_CHECK(h && name && data, "rald_dit_load_weight: null argument");
+    return h->impl.load_weight(name, data, nelem);
+}
+int rald_dit_finalize(rald_dit* h) { RALD_CHECK(h, "null handle"); return h->impl.finalize(); }
+int rald_dit_reserve(rald_dit* h, int32_t max_batch) {
+    RALD_CHECK(h && max_batch >= 1, "rald_dit_reserve: bad argument");
+    return h->impl.reserve(max_batch);
+}
+int rald_dit_set_sigmas(rald_dit* h, const float* sigmas_host, int32_t n, void* stream) {
+    RALD_CHECK(h && sigmas_host, "rald_dit_set_sigmas: null argument");
+    return h->impl.set_sigmas(sigmas_host, n, (hipStream_t)stream);
+}
+int64_t rald_dit_cond_cache_bytes(const rald_dit* h, int32_t batch) { return h ? h->impl.cond_cache_bytes(batch) : -1; }
+int rald_dit_encode_cond_tokens(rald_dit* h, const float* tokens, int32_t batch, void* cond_cache, void* stream) {
+    RALD_CHECK(h, "null handle");
+    return h->impl.encode_cond_tokens(tokens, batch, cond_cache, (hipStream_t)stream);
+}
+int rald_dit_encode_cond(rald_dit* h, const float* cube, int32_t batch, float* out_tokens, void* cond_cache, void* stream) {
+    RALD_CHECK(h && cube && cond_cache && batch >= 1, "rald_dit_encode_cond: bad argument");
+    return h->impl.encode_cond(cube, batch, out_tokens, cond_cache, (hipStream_t)stream);
+}
+int rald_dit_denoise(rald_dit* h, const float* x, int32_t batch, int32_t sigma_row, int32_t per_sample,
+                     const void* cond_cache, float* out, int32_t raw_F, void* stream) {
+    RALD_CHECK(h, "null handle");
+    return h->impl.denoise(x, batch, sigma_row, per_sample, cond_cache, out, raw_F, (hipStream_t)stream);
+}
+int rald_dit_sample(rald_dit* h, const float* latents, int32_t batch, const void* cond_cache, int32_t num_steps,
+                    float sigma_min, float sigma_max, float rho, float* out, void* stream) {
+    RALD_CHECK(h && latents && cond_cache && out && batch >= 1, "rald_dit_sample: bad argument");
+    return h->impl.sample(latents, batch, cond_cache, num_steps, sigma_min, sigma_max, rho, out, (hipStream_t)stream);
+}
+
+// ---- kernel-level entry points -----------------------------------------------------------------
+int rald_op_gemm_nt(const void* A, int64_t lda, int64_t strideA, const void* B, int64_t ldb, int64_t strideB,
+                    void* C, int64_t ldc, int64_t strideC, const float* bias, int32_t M, int32_t N, int32_t K,
+                    int32_t batch, float alpha, int32_t epilogue, void* stream) {
+    RALD_CHECK(A && B && C, "rald_op_gemm_nt: null pointer");
+    GemmArgs g;
+    g.A = (const bf16*)A; g.lda = lda; g.strideA = strideA; g.B = (const bf16*)B; g.ldb = ldb; g.strideB = strideB;
+    g.C = C; g.ldc = ldc; g.strideC = strideC; g.bias = bias; g.M = M; g.N = N; g.K = K; g.batch = batch; g.alpha = alpha;
+    return gemm_nt(g, epilogue, (hipStream_t)stream);
+}
+int rald_op_layernorm(const float* x, void* out_bf16, int32_t M, int32_t D, const float* g, const float* b,
+                      int64_t gstride, int32_t rows_per_group, float add_one, float eps, void* stream) {
+    RALD_CHECK(x && out_bf16 && g && b, "rald_op_layernorm: null pointer");
+    return layernorm_mod(x, (bf16*)out_bf16, M, D, g, b, gstride, rows_per_group, add_one, eps, (hipStream_t)stream);
+}
+int rald_op_attention(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK,
+                      const void* Vt, int64_t ldvt, int64_t strideVt, void* O, int64_t ldo, int64_t strideO,
+                      int32_t nq, int32_t nk, int32_t k_rows, int32_t heads, int32_t batch, float scale, void* stream) {
+    RALD_CHECK(Q && K && Vt && O, "rald_op_attention: null pointer");
+    AttnArgs a;
+    a.Q = (const bf16*)Q; a.ldq = ldq; a.strideQ = strideQ; a.K = (const bf16*)K; a.ldk = ldk; a.strideK = strideK;
+    a.Vt = (const bf16*)Vt; a.ldvt = ldvt; a.strideVt = strideVt; a.O = (bf16*)O; a.ldo = ldo; a.strideO = strideO;
+    a.nq = nq; a.nk = nk; a.k_rows = k_rows; a.heads = heads; a.batch = batch; a.scale = scale;
+    return attention_d64(a, (hipStream_t)stream);
+}
+int rald_op_cast_bf16(const float* in, void* out_bf16, int64_t n, void* stream) {
+    RALD_CHECK(in && out_bf16, "rald_op_cast_bf16: null pointer");
+    return cast_f32_bf16(in, (bf16*)out_bf16, n, (hipStream_t)stream);
+}
+
+}  // extern "C"

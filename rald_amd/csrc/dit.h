@@ -1,0 +1,93 @@
+// Host-side state of the denoiser handle (C++; the C-ABI wrappers live in api.hip).
+#pragma once
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/rald_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace rald {
+
+const char* last_error();
+
+struct DeviceArena {
+    std::vector<void*> ptrs;
+    void* alloc(size_t bytes, bool zero);
+    void release(void* p);
+    ~DeviceArena();
+};
+
+// fp32 host/device tensor -> packed device tensor (blocking; setup time only)
+struct Stager {
+    void* buf = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes);
+    int fetch(const float* data, int64_t nelem);
+    int to_bf16(const float* data, bf16* dst, int rows, int cols, int64_t ld_dst, const int* rowmap);
+    int to_f32(const float* data, float* dst, int rows, int cols, int64_t ld_dst, const int* rowmap);
+    ~Stager();
+};
+std::vector<int> geglu_rowmap(int inner);
+
+// ---- radar-spectrum encoder (radar.hip): model/models_radar_encoder.py Encoder + the
+// tokeniser half of EDMPrecond.process_radar_cond
+struct RadarEncoder {
+    struct Impl;
+    Impl* impl = nullptr;
+    int create(int ch, int z_ch, int R, int A, int E, int token_ch, DeviceArena* arena);
+    void expected_keys(const std::string& prefix, std::set<std::string>& out) const;
+    int load_weight(const std::string& name, const float* data, int64_t nelem, Stager& st);        // keys below "radar_enc."
+    int load_token_weight(const std::string& name, const float* data, int64_t nelem, Stager& st);  // radar_*_emb / radar_token_project
+    // cube [B,R,A,E,2] -> *tokens (handle-owned, [B, R/16*A/16*E/16, token_ch] fp32)
+    int tokens(const float* cube, int B, float** tokens, hipStream_t st);
+    // cube channel 0 -> encoder latent z [B, r, a, e, z_ch] fp32 (RadarAutoencoder._encode layout)
+    int encode(const float* cube, int cube_ch, int B, float** z, hipStream_t st);
+    ~RadarEncoder();
+};
+
+struct Dit {
+    rald_dit_config cfg;
+    int D = 512;
+    DeviceArena arena;
+    Stager stager;
+    struct Layer {
+        bf16 *w_qk, *w_v, *w_o, *w_q2, *w_o2, *w_ff1, *w_ff2;
+        float *b_o, *b_o2, *b_ff1, *b_ff2;
+    };
+    std::vector<Layer> layers;
+    bf16 *w_k2_all = nullptr, *w_v2_all = nullptr;      // attn2.to_k / to_v of every block stacked: [L*D, context_dim]
+    float *w_mod = nullptr, *b_mod = nullptr;           // all AdaLN linears stacked: [(L*3)*2D, D] fp32
+    float *w_t0 = nullptr, *b_t0 = nullptr, *w_t1 = nullptr, *b_t1 = nullptr;
+    float *w_in = nullptr, *w_out = nullptr, *norm_g = nullptr, *norm_b = nullptr, *coef_raw = nullptr;
+    int* d_geglu_map = nullptr;
+    RadarEncoder radar;
+    std::set<std::string> expected, loaded;
+    bool finalized = false;
+    // noise-level table
+    std::string sigma_key;
+    std::vector<float> h_sigma;
+    int n_sigma = 0, sig_cap = 0;
+    float *d_sigma = nullptr, *d_coef = nullptr, *d_cnoise = nullptr, *d_pe = nullptr, *d_temb0 = nullptr, *d_temb = nullptr,
+          *d_mod = nullptr;
+    int64_t mod_row() const { return (int64_t)cfg.depth * 3 * 2 * D; }
+    // activation workspace
+    int ws_batch = 0;
+    float *ws_x = nullptr, *ws_xcur = nullptr, *ws_xeul = nullptr, *ws_den = nullptr, *ws_dcur = nullptr;
+    bf16 *ws_h = nullptr, *ws_qk = nullptr, *ws_vt = nullptr, *ws_o = nullptr, *ws_q2 = nullptr, *ws_g = nullptr, *ws_tok = nullptr;
+
+    int create();
+    int load_weight(const std::string& name, const float* data, int64_t nelem);
+    int finalize();
+    int reserve(int B);
+    int set_sigmas(const float* sig, int n, hipStream_t st);
+    int64_t cond_cache_bytes(int B) const;
+    int encode_cond_tokens(const float* tokens, int B, void* cache, hipStream_t st);
+    int encode_cond(const float* cube, int B, float* out_tokens, void* cache, hipStream_t st);
+    int denoise(const float* x, int B, int sigma_row, int per_sample, const void* cache, float* out, int raw_F, hipStream_t st);
+    int sample(const float* latents, int B, const void* cache, int num_steps, float smin, float smax, float rho, float* out,
+               hipStream_t st);
+};
+
+}  // namespace rald

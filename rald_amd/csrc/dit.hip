@@ -1,0 +1,428 @@
+// Denoiser handle: weight packing, noise-level table, condition cache, one NFE, the Heun sampler.
+// Reference: model/models_radar_generation.py (LatentArrayTransformer :171-233, EDMPrecond
+// :314-449, edm_sampler :235-275).  See include/rald_hip.h for the C-ABI contract.
+#include "dit.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace rald {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+const char* last_error() { return g_err.c_str(); }
+
+// ---------------------------------------------------------------------------------------------
+// DeviceArena: owns every hipMalloc of a handle
+// ---------------------------------------------------------------------------------------------
+void* DeviceArena::alloc(size_t bytes, bool zero) {
+    void* p = nullptr;
+    if (bytes == 0) bytes = 16;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    if (zero) hipMemset(p, 0, bytes);
+    ptrs.push_back(p);
+    return p;
+}
+void DeviceArena::release(void* p) {
+    for (size_t i = 0; i < ptrs.size(); ++i)
+        if (ptrs[i] == p) {
+            hipFree(p);
+            ptrs.erase(ptrs.begin() + i);
+            return;
+        }
+}
+DeviceArena::~DeviceArena() {
+    for (void* p : ptrs) hipFree(p);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight staging: fp32 (host or device) -> packed device tensors
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_rows_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols,
+                                     int64_t ld_dst, const int* __restrict__ rowmap) {
+    const int r = blockIdx.x;
+    const int dr = rowmap ? rowmap[r] : r;
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) dst[(int64_t)dr * ld_dst + c] = src[(int64_t)r * cols + c];
+}
+
+int Stager::ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (buf) hipFree(buf);
+    buf = nullptr;
+    cap = 0;
+    RALD_HIP(hipMalloc(&buf, bytes));
+    cap = bytes;
+    return 0;
+}
+Stager::~Stager() {
+    if (buf) hipFree(buf);
+}
+int Stager::fetch(const float* data, int64_t nelem) {
+    RALD_TRY(ensure((size_t)nelem * 4));
+    RALD_HIP(hipMemcpy(buf, data, (size_t)nelem * 4, hipMemcpyDefault));
+    return 0;
+}
+int Stager::to_bf16(const float* data, bf16* dst, int rows, int cols, int64_t ld_dst, const int* rowmap) {
+    RALD_TRY(fetch(data, (int64_t)rows * cols));
+    RALD_TRY(pack_rows_bf16((const float*)buf, dst, rows, cols, ld_dst, rowmap, nullptr));
+    RALD_HIP(hipDeviceSynchronize());
+    return 0;
+}
+int Stager::to_f32(const float* data, float* dst, int rows, int cols, int64_t ld_dst, const int* rowmap) {
+    RALD_TRY(fetch(data, (int64_t)rows * cols));
+    hipLaunchKernelGGL(pack_rows_f32_kernel, dim3(rows), dim3(256), 0, nullptr, (const float*)buf, dst, rows, cols, ld_dst, rowmap);
+    RALD_HIP(hipGetLastError());
+    RALD_HIP(hipDeviceSynchronize());
+    return 0;
+}
+
+// GEGLU row packing (gemm.hip): x column c -> packed row 32*(c/16) + c%16, gate column c -> +16
+std::vector<int> geglu_rowmap(int inner) {
+    std::vector<int> m(2 * inner);
+    for (int c = 0; c < inner; ++c) {
+        m[c] = 32 * (c / 16) + c % 16;
+        m[inner + c] = 32 * (c / 16) + 16 + c % 16;
+    }
+    return m;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dit
+// ---------------------------------------------------------------------------------------------
+int Dit::create() {
+    const auto& c = cfg;
+    D = c.n_heads * c.d_head;
+    RALD_CHECK(c.d_head == 64, "dit: only d_head = 64 is implemented");
+    RALD_CHECK(D == 512, "dit: inner dim (n_heads*d_head) must be 512");
+    RALD_CHECK(c.n_latents > 0 && c.n_latents % 32 == 0, "dit: n_latents must be a positive multiple of 32");
+    RALD_CHECK(c.channels >= 1 && c.channels <= 64, "dit: channels must be in [1,64]");
+    RALD_CHECK(c.depth >= 1 && c.depth <= 256, "dit: bad depth");
+    RALD_CHECK(c.context_dim % 64 == 0 && c.context_dim > 0, "dit: context_dim must be a multiple of 64");
+    RALD_CHECK(c.n_cond_tokens > 0 && c.n_cond_tokens % 32 == 0, "dit: n_cond_tokens must be a multiple of 32");
+    RALD_CHECK(c.t_channels % 4 == 0, "dit: t_channels must be a multiple of 4");
+    const int L = c.depth;
+    layers.resize(L);
+    auto B16 = [&](size_t n) { return (bf16*)arena.alloc(n * 2, true); };
+    auto F32 = [&](size_t n) { return (float*)arena.alloc(n * 4, true); };
+    for (auto& l : layers) {
+        l.w_qk = B16((size_t)2 * D * D);
+        l.w_v = B16((size_t)D * D);
+        l.w_o = B16((size_t)D * D);
+        l.b_o = F32(D);
+        l.w_q2 = B16((size_t)D * D);
+        l.w_o2 = B16((size_t)D * D);
+        l.b_o2 = F32(D);
+        l.w_ff1 = B16((size_t)8 * D * D);
+        l.b_ff1 = F32((size_t)8 * D);
+        l.w_ff2 = B16((size_t)D * 4 * D);
+        l.b_ff2 = F32(D);
+    }
+    w_k2_all = B16((size_t)L * D * c.context_dim);
+    w_v2_all = B16((size_t)L * D * c.context_dim);
+    w_mod = F32((size_t)L * 3 * 2 * D * D);
+    b_mod = F32((size_t)L * 3 * 2 * D);
+    w_t0 = F32((size_t)D * c.t_channels);
+    b_t0 = F32(D);
+    w_t1 = F32((size_t)D * D);
+    b_t1 = F32(D);
+    w_in = F32((size_t)D * c.channels);
+    w_out = F32((size_t)c.channels * D);
+    norm_g = F32(D);
+    norm_b = F32(D);
+    coef_raw = F32(4);
+    std::vector<int> rm = geglu_rowmap(4 * D);
+    d_geglu_map = (int*)arena.alloc(rm.size() * 4, false);
+    RALD_CHECK(w_mod && d_geglu_map && coef_raw, "dit: device allocation failed");
+    RALD_HIP(hipMemcpy(d_geglu_map, rm.data(), rm.size() * 4, hipMemcpyHostToDevice));
+    const float raw[4] = {1.f, 0.f, 1.f, 0.f};   // c_in = 1, c_skip = 0, c_out = 1: plain F(x)
+    RALD_HIP(hipMemcpy(coef_raw, raw, sizeof(raw), hipMemcpyHostToDevice));
+    if (c.with_radar_enc) RALD_TRY(radar.create(c.enc_hidden_ch, c.enc_radar_ch, c.radar_r, c.radar_a, c.radar_e, D, &arena));
+    // expected keys
+    expected.clear();
+    char buf[160];
+    expected.insert("model.proj_in.weight");
+    for (int i = 0; i < L; ++i) {
+        static const char* names[] = {"attn1.to_q.weight", "attn1.to_k.weight", "attn1.to_v.weight", "attn1.to_out.0.weight",
+                                      "attn1.to_out.0.bias", "ff.net.0.proj.weight", "ff.net.0.proj.bias", "ff.net.2.weight",
+                                      "ff.net.2.bias", "attn2.to_q.weight", "attn2.to_k.weight", "attn2.to_v.weight",
+                                      "attn2.to_out.0.weight", "attn2.to_out.0.bias", "norm1.linear.weight", "norm1.linear.bias",
+                                      "norm2.linear.weight", "norm2.linear.bias", "norm3.linear.weight", "norm3.linear.bias"};
+        for (const char* n : names) {
+            snprintf(buf, sizeof(buf), "model.transformer_blocks.%d.%s", i, n);
+            expected.insert(buf);
+        }
+    }
+    for (const char* n : {"model.norm.weight", "model.norm.bias", "model.proj_out.weight", "model.map_layer0.weight",
+                          "model.map_layer0.bias", "model.map_layer1.weight", "model.map_layer1.bias"})
+        expected.insert(n);
+    if (c.with_radar_enc) radar.expected_keys("radar_enc.", expected);
+    if (c.with_radar_enc)
+        for (const char* n : {"radar_r_emb.weight", "radar_a_emb.weight", "radar_e_emb.weight", "radar_token_project.weight",
+                              "radar_token_project.bias"})
+            expected.insert(n);
+    return 0;
+}
+
+int Dit::load_weight(const std::string& name, const float* data, int64_t nelem) {
+    RALD_CHECK(expected.count(name), "dit: unexpected key '" + name + "'");
+    const auto& c = cfg;
+    auto need = [&](int64_t n) -> int {
+        RALD_CHECK(nelem == n, "dit: size mismatch for '" + name + "': got " + std::to_string(nelem) + ", expected " + std::to_string(n));
+        return 0;
+    };
+    int rc = 0;
+    int li = -1;
+    char tail[128] = {0};
+    if (name.rfind("radar_enc.", 0) == 0) {
+        rc = radar.load_weight(name.substr(10), data, nelem, stager);
+    } else if (name == "radar_r_emb.weight" || name == "radar_a_emb.weight" || name == "radar_e_emb.weight" ||
+               name == "radar_token_project.weight" || name == "radar_token_project.bias") {
+        rc = radar.load_token_weight(name, data, nelem, stager);
+    } else if (sscanf(name.c_str(), "model.transformer_blocks.%d.%127s", &li, tail) == 2) {
+        RALD_CHECK(li >= 0 && li < c.depth, "dit: block index out of range in '" + name + "'");
+        Layer& l = layers[li];
+        const std::string t(tail);
+        const int Cd = c.context_dim;
+        if (t == "attn1.to_q.weight") { RALD_TRY(need((int64_t)D * D)); rc = stager.to_bf16(data, l.w_qk, D, D, D, nullptr); }
+        else if (t == "attn1.to_k.weight") { RALD_TRY(need((int64_t)D * D)); rc = stager.to_bf16(data, l.w_qk + (size_t)D * D, D, D, D, nullptr); }
+        else if (t == "attn1.to_v.weight") { RALD_TRY(need((int64_t)D * D)); rc = stager.to_bf16(data, l.w_v, D, D, D, nullptr); }
+        else if (t == "attn1.to_out.0.weight") { RALD_TRY(need((int64_t)D * D)); rc = stager.to_bf16(data, l.w_o, D, D, D, nullptr); }
+        else if (t == "attn1.to_out.0.bias") { RALD_TRY(need(D)); rc = stager.to_f32(data, l.b_o, 1, D, D, nullptr); }
+        else if (t == "ff.net.0.proj.weight") { RALD_TRY(need((int64_t)8 * D * D)); rc = stager.to_bf16(data, l.w_ff1, 8 * D, D, D, d_geglu_map); }
+        else if (t == "ff.net.0.proj.bias") { RALD_TRY(need((int64_t)8 * D)); rc = stager.to_f32(data, l.b_ff1, 8 * D, 1, 1, d_geglu_map); }
+        else if (t == "ff.net.2.weight") { RALD_TRY(need((int64_t)D * 4 * D)); rc = stager.to_bf16(data, l.w_ff2, D, 4 * D, 4 * D, nullptr); }
+        else if (t == "ff.net.2.bias") { RALD_TRY(need(D)); rc = stager.to_f32(data, l.b_ff2, 1, D, D, nullptr); }
+        else if (t == "attn2.to_q.weight") { RALD_TRY(need((int64_t)D * D)); rc = stager.to_bf16(data, l.w_q2, D, D, D, nullptr); }
+        else if (t == "attn2.to_k.weight") { RALD_TRY(need((int64_t)D * Cd)); rc = stager.to_bf16(data, w_k2_all + (size_t)li * D * Cd, D, Cd, Cd, nullptr); }
+        else if (t == "attn2.to_v.weight") { RALD_TRY(need((int64_t)D * Cd)); rc = stager.to_bf16(data, w_v2_all + (size_t)li * D * Cd, D, Cd, Cd, nullptr); }
+        else if (t == "attn2.to_out.0.weight") { RALD_TRY(need((int64_t)D * D)); rc = stager.to_bf16(data, l.w_o2, D, D, D, nullptr); }
+        else if (t == "attn2.to_out.0.bias") { RALD_TRY(need(D)); rc = stager.to_f32(data, l.b_o2, 1, D, D, nullptr); }
+        else {
+            int j = -1;
+            char kind[16] = {0};
+            RALD_CHECK(sscanf(tail, "norm%d.linear.%15s", &j, kind) == 2 && j >= 1 && j <= 3, "dit: unknown key '" + name + "'");
+            const size_t slot = (size_t)li * 3 + (j - 1);
+            if (!strcmp(kind, "weight")) { RALD_TRY(need((int64_t)2 * D * D)); rc = stager.to_f32(data, w_mod + slot * 2 * D * D, 2 * D, D, D, nullptr); }
+            else { RALD_TRY(need((int64_t)2 * D)); rc = stager.to_f32(data, b_mod + slot * 2 * D, 1, 2 * D, 2 * D, nullptr); }
+        }
+    } else if (name == "model.proj_in.weight") { RALD_TRY(need((int64_t)D * c.channels)); rc = stager.to_f32(data, w_in, D, c.channels, c.channels, nullptr); }
+    else if (name == "model.proj_out.weight") { RALD_TRY(need((int64_t)c.channels * D)); rc = stager.to_f32(data, w_out, c.channels, D, D, nullptr); }
+    else if (name == "model.norm.weight") { RALD_TRY(need(D)); rc = stager.to_f32(data, norm_g, 1, D, D, nullptr); }
+    else if (name == "model.norm.bias") { RALD_TRY(need(D)); rc = stager.to_f32(data, norm_b, 1, D, D, nullptr); }
+    else if (name == "model.map_layer0.weight") { RALD_TRY(need((int64_t)D * c.t_channels)); rc = stager.to_f32(data, w_t0, D, c.t_channels, c.t_channels, nullptr); }
+    else if (name == "model.map_layer0.bias") { RALD_TRY(need(D)); rc = stager.to_f32(data, b_t0, 1, D, D, nullptr); }
+    else if (name == "model.map_layer1.weight") { RALD_TRY(need((int64_t)D * D)); rc = stager.to_f32(data, w_t1, D, D, D, nullptr); }
+    else if (name == "model.map_layer1.bias") { RALD_TRY(need(D)); rc = stager.to_f32(data, b_t1, 1, D, D, nullptr); }
+    else RALD_CHECK(false, "dit: unknown key '" + name + "'");
+    if (rc) return rc;
+    loaded.insert(name);
+    sigma_key.clear();   // any cached table depends on the weights
+    return 0;
+}
+
+int Dit::finalize() {
+    for (const auto& k : expected) RALD_CHECK(loaded.count(k), "dit: missing key '" + k + "' (strict load)");
+    finalized = true;
+    return 0;
+}
+
+int Dit::reserve(int B) {
+    if (B <= ws_batch) return 0;
+    RALD_HIP(hipDeviceSynchronize());
+    for (void* p : {(void*)ws_x, (void*)ws_h, (void*)ws_qk, (void*)ws_vt, (void*)ws_o, (void*)ws_q2, (void*)ws_g, (void*)ws_tok,
+                    (void*)ws_xcur, (void*)ws_xeul, (void*)ws_den, (void*)ws_dcur})
+        if (p) arena.release(p);
+    const size_t M = (size_t)B * cfg.n_latents;
+    const size_t nl = (size_t)B * cfg.n_latents * cfg.channels;
+    ws_x = (float*)arena.alloc(M * D * 4, true);
+    ws_h = (bf16*)arena.alloc(M * D * 2, true);
+    ws_qk = (bf16*)arena.alloc(M * 2 * D * 2, true);
+    ws_vt = (bf16*)arena.alloc((size_t)B * D * cfg.n_latents * 2, true);
+    ws_o = (bf16*)arena.alloc(M * D * 2, true);
+    ws_q2 = (bf16*)arena.alloc(M * D * 2, true);
+    ws_g = (bf16*)arena.alloc(M * 4 * D * 2, true);
+    ws_tok = (bf16*)arena.alloc((size_t)B * cfg.n_cond_tokens * cfg.context_dim * 2, true);
+    ws_xcur = (float*)arena.alloc(nl * 4, true);
+    ws_xeul = (float*)arena.alloc(nl * 4, true);
+    ws_den = (float*)arena.alloc(nl * 4, true);
+    ws_dcur = (float*)arena.alloc(nl * 4, true);
+    RALD_CHECK(ws_x && ws_h && ws_qk && ws_vt && ws_o && ws_q2 && ws_g && ws_tok && ws_xcur && ws_xeul && ws_den && ws_dcur,
+               "dit: workspace allocation failed");
+    ws_batch = B;
+    return 0;
+}
+
+// coef[s] = {c_in, c_skip, c_out, c_noise}  (EDMPrecond.forward :422-425, fp32 like the reference)
+__global__ void edm_coef_kernel(const float* __restrict__ sigma, float* __restrict__ coef, float* __restrict__ c_noise,
+                                int n, float sd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float s = sigma[i];
+    const float den = s * s + sd * sd;
+    coef[4 * i + 0] = 1.0f / sqrtf(den);
+    coef[4 * i + 1] = sd * sd / den;
+    coef[4 * i + 2] = s * sd / sqrtf(den);
+    const float cn = logf(s) / 4.0f;
+    coef[4 * i + 3] = cn;
+    c_noise[i] = cn;
+}
+
+int Dit::set_sigmas(const float* sig, int n, hipStream_t st) {
+    RALD_CHECK(finalized, "dit: weights not finalized");
+    RALD_CHECK(n >= 1 && n <= 4096, "dit: sigma table must have 1..4096 rows");
+    std::string key((const char*)sig, (size_t)n * 4);
+    if (key == sigma_key) return 0;
+    if (n > sig_cap) {
+        RALD_HIP(hipDeviceSynchronize());
+        for (void* p : {(void*)d_sigma, (void*)d_coef, (void*)d_cnoise, (void*)d_pe, (void*)d_temb0, (void*)d_temb, (void*)d_mod})
+            if (p) arena.release(p);
+        const int cap = n < 64 ? 64 : n;
+        d_sigma = (float*)arena.alloc((size_t)cap * 4, true);
+        d_coef = (float*)arena.alloc((size_t)cap * 16, true);
+        d_cnoise = (float*)arena.alloc((size_t)cap * 4, true);
+        d_pe = (float*)arena.alloc((size_t)cap * cfg.t_channels * 4, true);
+        d_temb0 = (float*)arena.alloc((size_t)cap * D * 4, true);
+        d_temb = (float*)arena.alloc((size_t)cap * D * 4, true);
+        d_mod = (float*)arena.alloc((size_t)cap * mod_row() * 4, true);
+        RALD_CHECK(d_sigma && d_coef && d_cnoise && d_pe && d_temb0 && d_temb && d_mod, "dit: sigma table allocation failed");
+        sig_cap = cap;
+    }
+    sigma_key.clear();
+    h_sigma.assign(sig, sig + n);   // the async copy below must not read a caller buffer that may go away
+    RALD_HIP(hipMemcpyAsync(d_sigma, h_sigma.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(edm_coef_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, d_sigma, d_coef, d_cnoise, n, cfg.sigma_data);
+    RALD_HIP(hipGetLastError());
+    RALD_TRY(positional_embedding(d_cnoise, d_pe, n, cfg.t_channels, st));
+    RALD_TRY(skinny_linear(d_pe, w_t0, b_t0, d_temb0, n, D, cfg.t_channels, ACT_SILU, st));
+    RALD_TRY(skinny_linear(d_temb0, w_t1, b_t1, d_temb, n, D, D, ACT_SILU, st));
+    RALD_TRY(skinny_linear(d_temb, w_mod, b_mod, d_mod, n, (int)mod_row(), D, ACT_NONE, st));
+    sigma_key = key;
+    n_sigma = n;
+    return 0;
+}
+
+int64_t Dit::cond_cache_bytes(int B) const {
+    // Kc [B*T][L*D] bf16  +  Vtc [B][L*D][T] bf16
+    return (int64_t)2 * B * cfg.n_cond_tokens * cfg.depth * D * 2;
+}
+
+int Dit::encode_cond_tokens(const float* tokens, int B, void* cache, hipStream_t st) {
+    RALD_CHECK(finalized, "dit: weights not finalized");
+    RALD_CHECK(B >= 1 && tokens && cache, "dit: bad arguments");
+    RALD_CHECK((uintptr_t)cache % 16 == 0, "dit: cond cache must be 16-byte aligned");
+    RALD_TRY(reserve(B));
+    const int T = cfg.n_cond_tokens, Cd = cfg.context_dim, L = cfg.depth;
+    RALD_TRY(cast_f32_bf16(tokens, ws_tok, (int64_t)B * T * Cd, st));
+    bf16* Kc = (bf16*)cache;
+    bf16* Vtc = Kc + (size_t)B * T * L * D;
+    // K for all blocks at once: [B*T, Cd] x [L*D, Cd]^T
+    GemmArgs g = gemm_args(ws_tok, Cd, w_k2_all, Cd, Kc, (int64_t)L * D, nullptr, B * T, L * D, Cd);
+    RALD_TRY(gemm_nt(g, EPI_BF16, st));
+    // V^T for all blocks: per sample [L*D, Cd] x [T, Cd]^T -> [L*D][T]
+    GemmArgs v = gemm_args(w_v2_all, Cd, ws_tok, Cd, Vtc, T, nullptr, L * D, T, Cd);
+    v.batch = B;
+    v.strideB = (int64_t)T * Cd;
+    v.strideC = (int64_t)L * D * T;
+    RALD_TRY(gemm_nt(v, EPI_BF16, st));
+    return 0;
+}
+
+int Dit::encode_cond(const float* cube, int B, float* out_tokens, void* cache, hipStream_t st) {
+    RALD_CHECK(cfg.with_radar_enc, "dit: handle was created without the radar encoder");
+    RALD_CHECK(finalized, "dit: weights not finalized");
+    float* tok = nullptr;
+    RALD_TRY(radar.tokens(cube, B, &tok, st));
+    if (out_tokens) RALD_HIP(hipMemcpyAsync(out_tokens, tok, (size_t)B * cfg.n_cond_tokens * D * 4, hipMemcpyDeviceToDevice, st));
+    return encode_cond_tokens(tok, B, cache, st);
+}
+
+int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const void* cache, float* out, int raw_F, hipStream_t st) {
+    RALD_CHECK(finalized, "dit: weights not finalized");
+    RALD_CHECK(B >= 1 && x && out && cache, "dit: bad arguments");
+    RALD_CHECK(!sigma_key.empty(), "dit: rald_dit_set_sigmas has not been called");
+    RALD_CHECK(sigma_row >= 0 && sigma_row + (per_sample ? B : 1) <= n_sigma, "dit: sigma_row out of range of the sigma table");
+    RALD_TRY(reserve(B));
+    const int NL = cfg.n_latents, T = cfg.n_cond_tokens, L = cfg.depth, C = cfg.channels;
+    const int M = B * NL;
+    const int64_t mrow = mod_row();
+    const float* mod = d_mod + (int64_t)sigma_row * mrow;
+    const int64_t gstride = per_sample ? mrow : 0;
+    const float* coef = raw_F ? coef_raw : d_coef + 4 * (int64_t)sigma_row;
+    const int cstride = (per_sample && !raw_F) ? 4 : 0;
+    const bf16* Kc = (const bf16*)cache;
+    const bf16* Vtc = Kc + (size_t)B * T * L * D;
+    const float scale = 1.0f / sqrtf((float)cfg.d_head);
+
+    RALD_TRY(proj_in(x, w_in, ws_x, M, C, D, coef, cstride, NL, st));
+    for (int li = 0; li < L; ++li) {
+        const Layer& l = layers[li];
+        const float* m1 = mod + (int64_t)(li * 3 + 0) * 2 * D;
+        const float* m2 = mod + (int64_t)(li * 3 + 1) * 2 * D;
+        const float* m3 = mod + (int64_t)(li * 3 + 2) * 2 * D;
+        // ---- x += attn1(norm1(x, t))                                               (:166)
+        RALD_TRY(layernorm_mod(ws_x, ws_h, M, D, m1, m1 + D, gstride, NL, 1.0f, 1e-5f, st));
+        GemmArgs qk = gemm_args(ws_h, D, l.w_qk, D, ws_qk, 2 * D, nullptr, M, 2 * D, D);
+        RALD_TRY(gemm_nt(qk, EPI_BF16, st));
+        GemmArgs vt = gemm_args(l.w_v, D, ws_h, D, ws_vt, NL, nullptr, D, NL, D);   // V^T = Wv . h^T per sample
+        vt.batch = B; vt.strideB = (int64_t)NL * D; vt.strideC = (int64_t)D * NL;
+        RALD_TRY(gemm_nt(vt, EPI_BF16, st));
+        AttnArgs a1;
+        a1.Q = ws_qk; a1.ldq = 2 * D; a1.strideQ = (int64_t)NL * 2 * D;
+        a1.K = ws_qk + D; a1.ldk = 2 * D; a1.strideK = (int64_t)NL * 2 * D;
+        a1.Vt = ws_vt; a1.ldvt = NL; a1.strideVt = (int64_t)D * NL;
+        a1.O = ws_o; a1.ldo = D; a1.strideO = (int64_t)NL * D;
+        a1.nq = NL; a1.nk = NL; a1.k_rows = NL; a1.heads = cfg.n_heads; a1.batch = B; a1.scale = scale;
+        RALD_TRY(attention_d64(a1, st));
+        GemmArgs o1 = gemm_args(ws_o, D, l.w_o, D, ws_x, D, l.b_o, M, D, D);
+        RALD_TRY(gemm_nt(o1, EPI_RESID, st));
+        // ---- x += attn2(norm2(x, t), context)                                      (:167)
+        RALD_TRY(layernorm_mod(ws_x, ws_h, M, D, m2, m2 + D, gstride, NL, 1.0f, 1e-5f, st));
+        GemmArgs q2 = gemm_args(ws_h, D, l.w_q2, D, ws_q2, D, nullptr, M, D, D);
+        RALD_TRY(gemm_nt(q2, EPI_BF16, st));
+        AttnArgs a2;
+        a2.Q = ws_q2; a2.ldq = D; a2.strideQ = (int64_t)NL * D;
+        a2.K = Kc + (size_t)li * D; a2.ldk = (int64_t)L * D; a2.strideK = (int64_t)T * L * D;
+        a2.Vt = Vtc + (size_t)li * D * T; a2.ldvt = T; a2.strideVt = (int64_t)L * D * T;
+        a2.O = ws_o; a2.ldo = D; a2.strideO = (int64_t)NL * D;
+        a2.nq = NL; a2.nk = T; a2.k_rows = T; a2.heads = cfg.n_heads; a2.batch = B; a2.scale = scale;
+        RALD_TRY(attention_d64(a2, st));
+        GemmArgs o2 = gemm_args(ws_o, D, l.w_o2, D, ws_x, D, l.b_o2, M, D, D);
+        RALD_TRY(gemm_nt(o2, EPI_RESID, st));
+        // ---- x += ff(norm3(x, t))                                                   (:168)
+        RALD_TRY(layernorm_mod(ws_x, ws_h, M, D, m3, m3 + D, gstride, NL, 1.0f, 1e-5f, st));
+        GemmArgs f1 = gemm_args(ws_h, D, l.w_ff1, D, ws_g, 4 * D, l.b_ff1, M, 8 * D, D);
+        RALD_TRY(gemm_nt(f1, EPI_GEGLU, st));
+        GemmArgs f2 = gemm_args(ws_g, 4 * D, l.w_ff2, 4 * D, ws_x, D, l.b_ff2, M, D, 4 * D);
+        RALD_TRY(gemm_nt(f2, EPI_RESID, st));
+    }
+    RALD_TRY(final_norm_proj(ws_x, norm_g, norm_b, w_out, x, out, M, D, C, coef, cstride, NL, st));
+    return 0;
+}
+
+int Dit::sample(const float* latents, int B, const void* cache, int num_steps, float smin, float smax, float rho,
+                float* out, hipStream_t st) {
+    RALD_CHECK(num_steps >= 2 && num_steps <= 2048, "dit: num_steps must be in [2,2048]");
+    // Karras schedule in fp32, as the reference computes it (edm_sampler :246-249); t_N = 0.
+    std::vector<float> t(num_steps + 1);
+    const float a = powf(smax, 1.0f / rho), b = powf(smin, 1.0f / rho);
+    for (int i = 0; i < num_steps; ++i) t[i] = powf(a + (float)i / (float)(num_steps - 1) * (b - a), rho);
+    t[num_steps] = 0.f;
+    RALD_TRY(reserve(B));
+    RALD_TRY(set_sigmas(t.data(), num_steps, st));
+    const int64_t n = (int64_t)B * cfg.n_latents * cfg.channels;
+    RALD_TRY(scale_f32(latents, ws_xcur, t[0], n, st));                              // x_next = latents * t_0
+    for (int i = 0; i < num_steps; ++i) {
+        const float tc = t[i], tn = t[i + 1];
+        RALD_TRY(denoise(ws_xcur, B, i, 0, cache, ws_den, 0, st));                   // Euler step (:263-266)
+        const bool last = i == num_steps - 1;
+        RALD_TRY(heun_euler(ws_xcur, ws_den, tc, tn, ws_dcur, last ? out : ws_xeul, n, st));
+        if (!last) {                                                                 // 2nd-order correction (:269-273)
+            RALD_TRY(denoise(ws_xeul, B, i + 1, 0, cache, ws_den, 0, st));
+            RALD_TRY(heun_correct(ws_xcur, ws_xeul, ws_den, ws_dcur, tc, tn, ws_xcur, n, st));   // in place, elementwise
+        }
+    }
+    return 0;
+}
+
+}  // namespace rald

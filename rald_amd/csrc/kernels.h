@@ -42,6 +42,7 @@ struct AttnArgs {
     const bf16* Vt; int64_t ldvt, strideVt;    // Vt[b][h*64+d][j]  (keys contiguous, zero padded to 32)
     bf16* O;        int64_t ldo,  strideO;     // O [b][i][h*64+d]
     int nq, nk, heads, batch;
+    int k_rows;                                // rows allocated per batch in K (>= round_up(nk,32): the tail tile reads them)
     float scale;
 };
 int attention_d64(const AttnArgs& a, hipStream_t st);

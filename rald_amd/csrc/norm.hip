@@ -1,0 +1,169 @@
+// Row-wise kernels over the fp32 residual stream x[M][D] (HBM-bound: one wave per row, every
+// global access a fully coalesced 16-byte-per-lane instruction).
+//
+//   layernorm_mod   LN(x) * (add_one + g) + b -> bf16   : AdaLayerNorm (models_radar_generation.py
+//                   :127-131, g = scale, b = shift, add_one = 1, per-sample or shared modulation
+//                   rows) and plain affine LayerNorm (models_ae.py:38-42, g = weight, b = bias).
+//   proj_in         x = c_in * xin @ W^T                : :221 fused with EDM c_in (:424,:427)
+//   final_norm_proj D = c_skip*xin + c_out*(LN_affine(x) @ Wout^T) : :230-232 fused with :429
+#include "common.h"
+#include "kernels.h"
+
+namespace rald {
+
+// Lane l of the row's wave owns float4 chunks l, l+64, ... (VPL/4 chunks).
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm_mod_kernel(const float* __restrict__ x, bf16* __restrict__ out,
+                                                            int M, const float* __restrict__ g, const float* __restrict__ b,
+                                                            int64_t gstride, int rows_per_group, float add_one, float eps) {
+    constexpr int NC = VPL / 4;
+    constexpr int D = VPL * 64;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
+    float4 v[NC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        v[c] = xr[lane + 64 * c];
+        s += v[c].x + v[c].y + v[c].z + v[c].w;
+    }
+    const float mean = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float dx = v[c].x - mean, dy = v[c].y - mean, dz = v[c].z - mean, dw = v[c].w - mean;
+        q += dx * dx + dy * dy + dz * dz + dw * dw;
+    }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + eps);     // biased variance, as torch LN
+    const int64_t goff = (int64_t)(row / rows_per_group) * gstride;
+    const float4* gr = reinterpret_cast<const float4*>(g + goff);
+    const float4* br = reinterpret_cast<const float4*>(b + goff);
+    bf16x4* orow = reinterpret_cast<bf16x4*>(out + (int64_t)row * D);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float4 gg = gr[lane + 64 * c], bb = br[lane + 64 * c];
+        orow[lane + 64 * c] = pack4((v[c].x - mean) * rstd * (add_one + gg.x) + bb.x,
+                                    (v[c].y - mean) * rstd * (add_one + gg.y) + bb.y,
+                                    (v[c].z - mean) * rstd * (add_one + gg.z) + bb.z,
+                                    (v[c].w - mean) * rstd * (add_one + gg.w) + bb.w);
+    }
+}
+
+int layernorm_mod(const float* x, bf16* out, int M, int D, const float* g, const float* b,
+                  int64_t gstride, int rows_per_group, float add_one, float eps, hipStream_t st) {
+    RALD_CHECK(M > 0 && rows_per_group > 0, "layernorm: empty");
+    RALD_CHECK(D == 256 || D == 512 || D == 1024, "layernorm: D must be 256, 512 or 1024");
+    dim3 grid(cdiv(M, 4)), block(256);
+    if (D == 256) hipLaunchKernelGGL((layernorm_mod_kernel<4>), grid, block, 0, st, x, out, M, g, b, gstride, rows_per_group, add_one, eps);
+    else if (D == 512) hipLaunchKernelGGL((layernorm_mod_kernel<8>), grid, block, 0, st, x, out, M, g, b, gstride, rows_per_group, add_one, eps);
+    else hipLaunchKernelGGL((layernorm_mod_kernel<16>), grid, block, 0, st, x, out, M, g, b, gstride, rows_per_group, add_one, eps);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- proj_in: K = C (latent channels, <= 64) is far too small for MFMA; fp32 FMA, 8 rows per WG.
+__global__ __launch_bounds__(256) void proj_in_kernel(const float* __restrict__ xin, const float* __restrict__ W,
+                                                      float* __restrict__ x, int M, int C, int D,
+                                                      const float* __restrict__ coef, int coef_stride, int rows_per_group) {
+    __shared__ float sx[8][64];
+    const int m0 = blockIdx.x * 8;
+    for (int i = threadIdx.x; i < 8 * C; i += 256) {
+        int r = i / C, c = i % C, m = m0 + r;
+        float v = 0.f;
+        if (m < M) v = xin[(int64_t)m * C + c] * coef[(int64_t)(m / rows_per_group) * coef_stride + 0];
+        sx[r][c] = v;
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < D; n += 256) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const float* w = W + (int64_t)n * C;
+        for (int c = 0; c < C; ++c) {
+            float wv = w[c];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] += sx[r][c] * wv;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (m0 + r < M) x[(int64_t)(m0 + r) * D + n] = acc[r];
+    }
+}
+
+int proj_in(const float* xin, const float* W, float* x, int M, int C, int D, const float* coef,
+            int coef_stride, int rows_per_group, hipStream_t st) {
+    RALD_CHECK(C >= 1 && C <= 64, "proj_in: latent channels must be in [1,64]");
+    hipLaunchKernelGGL(proj_in_kernel, dim3(cdiv(M, 8)), dim3(256), 0, st, xin, W, x, M, C, D, coef, coef_stride, rows_per_group);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- final LayerNorm(affine) + proj_out (D -> C, no bias) + EDM skip/out scaling, all fp32:
+// this is the network's output layer, so nothing here is rounded to bf16.
+template <int VPL>
+__global__ __launch_bounds__(256) void final_norm_proj_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ Wout,
+                                                              const float* __restrict__ xin, float* __restrict__ out, int M, int C,
+                                                              const float* __restrict__ coef, int coef_stride, int rows_per_group) {
+    constexpr int NC = VPL / 4;
+    constexpr int D = VPL * 64;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
+    float4 v[NC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        v[c] = xr[lane + 64 * c];
+        s += v[c].x + v[c].y + v[c].z + v[c].w;
+    }
+    const float mean = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float dx = v[c].x - mean, dy = v[c].y - mean, dz = v[c].z - mean, dw = v[c].w - mean;
+        q += dx * dx + dy * dy + dz * dz + dw * dw;
+    }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + 1e-5f);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float4 gg = reinterpret_cast<const float4*>(gamma)[lane + 64 * c];
+        float4 bb = reinterpret_cast<const float4*>(beta)[lane + 64 * c];
+        v[c].x = (v[c].x - mean) * rstd * gg.x + bb.x;
+        v[c].y = (v[c].y - mean) * rstd * gg.y + bb.y;
+        v[c].z = (v[c].z - mean) * rstd * gg.z + bb.z;
+        v[c].w = (v[c].w - mean) * rstd * gg.w + bb.w;
+    }
+    const float* cf = coef + (int64_t)(row / rows_per_group) * coef_stride;
+    const float c_skip = cf[1], c_out = cf[2];
+    float mine = 0.f;                                   // lane c keeps output channel c
+    for (int c = 0; c < C; ++c) {
+        const float4* w = reinterpret_cast<const float4*>(Wout + (int64_t)c * D);
+        float p = 0.f;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            float4 ww = w[lane + 64 * k];
+            p += v[k].x * ww.x + v[k].y * ww.y + v[k].z * ww.z + v[k].w * ww.w;
+        }
+        p = wave_sum(p);
+        if (lane == c) mine = p;
+    }
+    if (lane < C) {
+        const int64_t o = (int64_t)row * C + lane;
+        out[o] = c_skip * xin[o] + c_out * mine;
+    }
+}
+
+int final_norm_proj(const float* x, const float* gamma, const float* beta, const float* Wout,
+                    const float* xin, float* out, int M, int D, int C, const float* coef,
+                    int coef_stride, int rows_per_group, hipStream_t st) {
+    RALD_CHECK(C >= 1 && C <= 64, "final_norm_proj: output channels must be in [1,64]");
+    RALD_CHECK(D == 512, "final_norm_proj: D must be 512");
+    hipLaunchKernelGGL((final_norm_proj_kernel<8>), dim3(cdiv(M, 4)), dim3(256), 0, st, x, gamma, beta, Wout, xin, out, M, C,
+                       coef, coef_stride, rows_per_group);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace rald

@@ -1,0 +1,148 @@
+// Small fp32 kernels around the MFMA path: the timestep-embedding MLP and the AdaLN modulation
+// GEMV (M = number of distinct sigmas, tiny), casts / weight packing, and the elementwise
+// Heun updates of the EDM sampler.  All HBM- or latency-bound; coalesced 16-byte accesses.
+#include "common.h"
+#include "kernels.h"
+
+namespace rald {
+
+// ---- PositionalEmbedding (models_radar_generation.py:27-33): cat[cos, sin] of t * (1/10000)^(i/half)
+__global__ void posemb_kernel(const float* __restrict__ t, float* __restrict__ pe, int S, int channels) {
+    const int half = channels / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S * half) return;
+    const int s = i / half, k = i % half;
+    const float f = powf(1.0f / 10000.0f, (float)k / (float)half);
+    const float arg = t[s] * f;
+    pe[(int64_t)s * channels + k] = cosf(arg);
+    pe[(int64_t)s * channels + half + k] = sinf(arg);
+}
+int positional_embedding(const float* c_noise, float* pe, int S, int channels, hipStream_t st) {
+    RALD_CHECK(S > 0 && channels % 2 == 0, "posemb: bad shape");
+    const int n = S * channels / 2;
+    hipLaunchKernelGGL(posemb_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, c_noise, pe, S, channels);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- skinny linear: one wave per output feature n, the K axis spread over the 64 lanes as
+// float4 chunks (coalesced weight stream - the kernel is bound by reading W once), S rows looped.
+template <int MAXS>
+__global__ __launch_bounds__(256) void skinny_linear_kernel(const float* __restrict__ in, const float* __restrict__ W,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            int S, int N, int K, int act) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float acc[MAXS];
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) acc[s] = 0.f;
+    const float4* w = reinterpret_cast<const float4*>(W + (int64_t)n * K);
+    for (int c = lane; c < K / 4; c += 64) {
+        const float4 ww = w[c];
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) {
+            if (s < S) {
+                const float4 xx = reinterpret_cast<const float4*>(in + (int64_t)s * K)[c];
+                acc[s] += xx.x * ww.x + xx.y * ww.y + xx.z * ww.z + xx.w * ww.w;
+            }
+        }
+    }
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+        if (s < S) {
+            float v = wave_sum(acc[s]) + bv;
+            if (act == ACT_SILU) v = silu(v);
+            if (lane == 0) out[(int64_t)s * N + n] = v;
+        }
+    }
+}
+int skinny_linear(const float* in, const float* W, const float* bias, float* out, int S, int N, int K,
+                  int act, hipStream_t st) {
+    RALD_CHECK(S > 0 && N > 0 && K > 0 && K % 4 == 0, "skinny_linear: bad shape");
+    dim3 grid(cdiv(N, 4)), block(256);
+    // rows are processed in chunks of 8 so the per-lane accumulators stay in registers
+    for (int s0 = 0; s0 < S; s0 += 8) {
+        const int sc = S - s0 < 8 ? S - s0 : 8;
+        hipLaunchKernelGGL((skinny_linear_kernel<8>), grid, block, 0, st, in + (int64_t)s0 * K, W, bias, out + (int64_t)s0 * N, sc, N, K, act);
+    }
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- casts / packing ------------------------------------------------------------------------
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ in, bf16* __restrict__ out, int64_t n4) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        float4 v = reinterpret_cast<const float4*>(in)[i];
+        reinterpret_cast<bf16x4*>(out)[i] = pack4(v.x, v.y, v.z, v.w);
+    }
+}
+int cast_f32_bf16(const float* in, bf16* out, int64_t n, hipStream_t st) {
+    RALD_CHECK(n > 0 && n % 4 == 0, "cast: n must be a positive multiple of 4");
+    const int64_t n4 = n / 4;
+    int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(blocks), dim3(256), 0, st, in, out, n4);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void pack_rows_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int rows, int cols,
+                                      int64_t ld_dst, const int* __restrict__ rowmap) {
+    const int r = blockIdx.x;
+    const int dr = rowmap ? rowmap[r] : r;
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) dst[(int64_t)dr * ld_dst + c] = (bf16)src[(int64_t)r * cols + c];
+}
+int pack_rows_bf16(const float* src, bf16* dst, int rows, int cols, int64_t ld_dst, const int* rowmap, hipStream_t st) {
+    RALD_CHECK(rows > 0 && cols > 0 && ld_dst >= cols, "pack_rows: bad shape");
+    hipLaunchKernelGGL(pack_rows_bf16_kernel, dim3(rows), dim3(256), 0, st, src, dst, rows, cols, ld_dst, rowmap);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void scale_kernel(const float* __restrict__ in, float* __restrict__ out, float s, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] * s;
+}
+int scale_f32(const float* in, float* out, float s, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, s, n);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- Heun (2nd-order) sampler updates, same fp32 operation order as the reference ------------
+//   d_cur  = (x_hat - denoised) / t_hat ;  x_next = x_hat + (t_next - t_hat) * d_cur      (:265-266)
+__global__ void heun_euler_kernel(const float* __restrict__ x_hat, const float* __restrict__ den, float t_hat,
+                                  float t_next, float* __restrict__ d_cur, float* __restrict__ x_next, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float xh = x_hat[i];
+    const float d = (xh - den[i]) / t_hat;
+    d_cur[i] = d;
+    x_next[i] = xh + (t_next - t_hat) * d;
+}
+int heun_euler(const float* x_hat, const float* denoised, float t_hat, float t_next, float* d_cur,
+               float* x_next, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(heun_euler_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x_hat, denoised, t_hat, t_next, d_cur, x_next, n);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+//   d_prime = (x_euler - denoised) / t_next ; x_next = x_hat + (t_next - t_hat)*(0.5 d_cur + 0.5 d_prime)  (:272-273)
+__global__ void heun_correct_kernel(const float* __restrict__ x_hat, const float* __restrict__ x_euler,
+                                    const float* __restrict__ den, const float* __restrict__ d_cur, float t_hat,
+                                    float t_next, float* __restrict__ x_next, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float dp = (x_euler[i] - den[i]) / t_next;
+    x_next[i] = x_hat[i] + (t_next - t_hat) * (0.5f * d_cur[i] + 0.5f * dp);
+}
+int heun_correct(const float* x_hat, const float* x_euler, const float* denoised, const float* d_cur,
+                 float t_hat, float t_next, float* x_next, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(heun_correct_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x_hat, x_euler, denoised, d_cur, t_hat, t_next, x_next, n);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace rald

@@ -1,0 +1,307 @@
+"""Drop-in for the reference's ``model/models_radar_generation.py``: same factory names
+(``kl_d512_m512_l32_d24_edm`` ..., looked up via ``__dict__[name](configs=...)``,
+main_generation.py:122), same ``EDMPrecond`` constructor / ``forward`` / ``sample`` /
+``process_radar_cond`` signatures (:314-449), same ``edm_sampler`` (:235-275), ``EDMLoss``
+(:277-295), ``StackedRandomGenerator`` (:297-311) and the same ``state_dict`` keys, so the
+reference's checkpoints load with ``strict=True`` (utils/misc.py:346).
+
+The modules hold fp32 ``nn.Parameter``s only; every forward runs the hand-written HIP kernels of
+``librald_hip.so`` through the C-ABI (include/rald_hip.h).  There is no PyTorch compute path: on
+a CPU tensor, or without the library, calls raise.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import weights as _w
+from ._handles import DitHandle
+from ._lib import DitConfig
+
+
+# ----------------------------------------------------------------------------------------------
+# parameter containers with the reference's key names
+# ----------------------------------------------------------------------------------------------
+def _init_param(name: str, shape) -> torch.Tensor:
+    """Fresh-module initialisation in the spirit of the reference's torch defaults: uniform
+    +-1/sqrt(fan_in) for weights and biases of Linear/Conv, ones/zeros for norms, N(0,1) for
+    embeddings, and the zero-initialised proj_out (:198-201)."""
+    if name.endswith("proj_out.weight") and "attn" not in name:
+        return torch.zeros(shape)
+    if name.endswith("_emb.weight") or name.endswith("latents.weight"):
+        return torch.randn(shape)
+    if len(shape) >= 2:
+        bound = 1.0 / math.sqrt(int(np.prod(shape[1:])))
+        return torch.empty(shape).uniform_(-bound, bound)
+    if ".norm" in name or name.startswith("norm"):
+        return torch.ones(shape) if name.endswith("weight") else torch.zeros(shape)
+    return torch.zeros(shape)
+
+
+def build_param_tree(root: nn.Module, spec, buffers=()) -> None:
+    """Registers every (dotted name, shape) of `spec` under `root` as nested plain nn.Modules so
+    that ``root.state_dict()`` has exactly the reference's keys, in the reference's order."""
+    for name, shape in spec:
+        parts = name.split(".")
+        mod = root
+        for p in parts[:-1]:
+            if p not in mod._modules:
+                mod.add_module(p, nn.Module())
+            mod = mod._modules[p]
+        if name in buffers:
+            mod.register_buffer(parts[-1], _w.seeded_tensor(0, name, shape))
+        else:
+            mod.register_parameter(parts[-1], nn.Parameter(_init_param(name, tuple(shape))))
+
+
+class _HipBacked(nn.Module):
+    """Mixin: lazily creates the C handle on the parameters' device and re-packs the weights
+    whenever a parameter/buffer changed (load_state_dict, optimizer step, .to())."""
+
+    def _state_fingerprint(self):
+        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+
+    def _device(self) -> torch.device:
+        return next(self.parameters()).device
+
+
+# ----------------------------------------------------------------------------------------------
+# LatentArrayTransformer (:171-233)
+# ----------------------------------------------------------------------------------------------
+class LatentArrayTransformer(_HipBacked):
+    def __init__(self, in_channels, t_channels, n_heads, d_head, depth=1, dropout=0., context_dim=None,
+                 out_channels=None, _owner=None):
+        super().__init__()
+        if dropout != 0.:
+            raise NotImplementedError("dropout > 0 is not on the reference's shipped path")
+        if out_channels is not None:
+            raise NotImplementedError("out_channels is never set by the reference's factories")
+        self.in_channels = in_channels
+        self.t_channels = t_channels
+        self.context_dim = context_dim
+        self.depth, self.n_heads, self.d_head = depth, n_heads, d_head
+        object.__setattr__(self, "_owner", _owner)      # EDMPrecond that shares its handle (not a submodule)
+        self._hip = None
+        self._hip_fp = None
+        spec = _w.dit_spec(channels=in_channels, depth=depth, n_heads=n_heads, d_head=d_head, t_channels=t_channels,
+                           context_dim=context_dim, with_radar=False, prefix="")
+        build_param_tree(self, spec)
+
+    def _config(self, n_latents=512, n_cond_tokens=64) -> DitConfig:
+        D = self.n_heads * self.d_head
+        return DitConfig(n_latents=n_latents, channels=self.in_channels, depth=self.depth, n_heads=self.n_heads,
+                         d_head=self.d_head, t_channels=self.t_channels,
+                         context_dim=D if self.context_dim is None else self.context_dim,
+                         n_cond_tokens=n_cond_tokens, with_radar_enc=0, enc_hidden_ch=64, enc_radar_ch=16,
+                         radar_r=128, radar_a=64, radar_e=32, sigma_data=1.0)
+
+    def _handle(self, n_latents: int, n_cond_tokens: int) -> DitHandle:
+        if self._owner is not None:
+            return self._owner._handle()
+        fp = (self._state_fingerprint(), n_latents, n_cond_tokens)
+        if self._hip is None or self._hip_fp != fp:
+            h = DitHandle(self._config(n_latents, n_cond_tokens))
+            h.load(("model." + k, v) for k, v in self.state_dict().items())
+            self._hip, self._hip_fp = h, fp
+        return self._hip
+
+    def forward(self, x, t, cond=None):
+        """x [B,N,C], t [B'] (= c_noise; B' = 1 or B), cond [B,T,context_dim] -> F_x [B,N,C]."""
+        if cond is None:
+            raise NotImplementedError("the reference always passes radar condition tokens (cond)")
+        h = self._handle(x.shape[1], cond.shape[1])
+        t = torch.as_tensor(t, dtype=torch.float32).flatten().cpu()
+        h.set_sigmas(torch.exp(4.0 * t.double()).tolist())      # c_noise = ln(sigma)/4  (:425)
+        cache = h.encode_cond_tokens(cond)
+        return h.denoise(x, cache, 0, per_sample=t.numel() > 1, raw_F=True)
+
+
+# ----------------------------------------------------------------------------------------------
+# sampler / loss / RNG helpers
+# ----------------------------------------------------------------------------------------------
+def edm_sampler(net, latents, class_labels=None, cond_type=None, randn_like=torch.randn_like,
+                num_steps=18, sigma_min=0.002, sigma_max=80, rho=7,
+                S_churn=0, S_min=0, S_max=float('inf'), S_noise=1):
+    """Same signature as the reference (:235-240).  With the shipped S_churn=0 the whole loop
+    (2*num_steps-1 NFEs + Heun updates) runs inside librald_hip.so with the radar condition
+    encoded once; `randn_like` is never consumed because the reference multiplies it by exactly
+    0 (:258-260).  S_churn > 0 is not on the reference's path and is rejected."""
+    if S_churn != 0:
+        raise NotImplementedError("S_churn > 0: the reference ships S_churn=0 (:239)")
+    sigma_min = max(sigma_min, net.sigma_min)
+    sigma_max = min(sigma_max, net.sigma_max)
+    return net._sample_from(latents, class_labels, cond_type, num_steps, sigma_min, sigma_max, rho)
+
+
+class EDMLoss:
+    """:277-295.  Forward value only in this round (the backward/optimizer path is SURVEY.md
+    §8f rank 1, 'next')."""
+
+    def __init__(self, P_mean=-1.2, P_std=1.2, sigma_data=1):
+        self.P_mean, self.P_std, self.sigma_data = P_mean, P_std, sigma_data
+
+    def __call__(self, net, inputs, labels=None, cond_type=None, augment_pipe=None):
+        rnd_normal = torch.randn([inputs.shape[0], 1, 1], device=inputs.device)
+        sigma = (rnd_normal * self.P_std + self.P_mean).exp()
+        weight = (sigma ** 2 + self.sigma_data ** 2) / (sigma * self.sigma_data) ** 2
+        y, _ = augment_pipe(inputs) if augment_pipe is not None else (inputs, None)
+        n = torch.randn_like(y) * sigma
+        D_yn = net(y + n, sigma, labels, cond_type)
+        return (weight * ((D_yn - y) ** 2)).mean()
+
+
+class StackedRandomGenerator:
+    """:297-311.  Generators live on the CPU: device generator streams differ between CPU, CUDA
+    and HIP, and 'identical noise seeds' against the reference's CPU path means the CPU stream
+    (SURVEY.md §8b RNG); draws are moved to `device` afterwards."""
+
+    def __init__(self, device, seeds):
+        self.device = device
+        self.generators = [torch.Generator("cpu").manual_seed(int(seed) % (1 << 32)) for seed in seeds]
+
+    def randn(self, size, **kwargs):
+        assert size[0] == len(self.generators)
+        kwargs.pop("device", None)
+        return torch.stack([torch.randn(size[1:], generator=gen, **kwargs) for gen in self.generators]).to(self.device)
+
+    def randn_like(self, input):
+        return self.randn(input.shape, dtype=input.dtype, layout=input.layout)
+
+    def randint(self, *args, size, **kwargs):
+        assert size[0] == len(self.generators)
+        kwargs.pop("device", None)
+        return torch.stack([torch.randint(*args, size=size[1:], generator=gen, **kwargs) for gen in self.generators]).to(self.device)
+
+
+# ----------------------------------------------------------------------------------------------
+# EDMPrecond (:314-449)
+# ----------------------------------------------------------------------------------------------
+class EDMPrecond(_HipBacked):
+    def __init__(self, n_latents=512, channels=8, use_fp16=False, sigma_min=0, sigma_max=float('inf'),
+                 sigma_data=1, n_heads=8, d_head=64, depth=12, configs=None):
+        super().__init__()
+        if use_fp16:
+            raise NotImplementedError("use_fp16 is never set by the reference (fp32 end to end, :318)")
+        self.n_latents, self.channels, self.use_fp16 = n_latents, channels, use_fp16
+        self.sigma_min, self.sigma_max, self.sigma_data = sigma_min, sigma_max, sigma_data
+        self.configs = configs
+        self.n_heads, self.d_head, self.depth = n_heads, d_head, depth
+        self.unfreeze_radar_enc = self.configs.get('unfreeze_radar_enc', False)
+        if configs.cond_type != 'radar':
+            raise NotImplementedError("only cond_type='radar' exists in the reference (:341)")
+        if not (self.unfreeze_radar_enc and self.configs.use_radar_enc):
+            raise NotImplementedError("the shipped config trains the radar encoder jointly "
+                                      "(use_radar_enc=True, unfreeze_radar_enc=True); the frozen-encoder "
+                                      "route is not built yet")
+        self.radar_token_channel = self.configs.radar_token_channel
+        self.model = LatentArrayTransformer(in_channels=channels, t_channels=256, n_heads=n_heads, d_head=d_head,
+                                            depth=depth, _owner=self)
+        rest = _w.dit_spec(channels=channels, depth=0, with_radar=True, enc_hidden_ch=self.configs.enc_hidden_ch,
+                           enc_radar_ch=self.configs.enc_radar_ch, radar_token_channel=self.radar_token_channel,
+                           rae=(self.configs.enc_radar_r_dim, self.configs.enc_radar_a_dim, self.configs.enc_radar_e_dim))
+        build_param_tree(self, [(n, s) for n, s in rest if not n.startswith("model.")])
+        self._hip = None
+        self._hip_fp = None
+        self._cond_memo = None
+
+    # -- handle -----------------------------------------------------------------------------
+    def _config(self) -> DitConfig:
+        c = self.configs
+        return DitConfig(n_latents=self.n_latents, channels=self.channels, depth=self.depth, n_heads=self.n_heads,
+                         d_head=self.d_head, t_channels=256, context_dim=self.radar_token_channel,
+                         n_cond_tokens=c.enc_radar_r_dim * c.enc_radar_a_dim * c.enc_radar_e_dim, with_radar_enc=1,
+                         enc_hidden_ch=c.enc_hidden_ch, enc_radar_ch=c.enc_radar_ch, radar_r=c.input_radar_r_dim,
+                         radar_a=c.input_radar_a_dim, radar_e=c.input_radar_e_dim, sigma_data=float(self.sigma_data))
+
+    def _handle(self) -> DitHandle:
+        fp = self._state_fingerprint()
+        if self._hip is None or self._hip_fp != fp:
+            h = DitHandle(self._config())
+            h.load(self.state_dict().items())
+            self._hip, self._hip_fp, self._cond_memo = h, fp, None
+        return self._hip
+
+    def _cond(self, cube: torch.Tensor):
+        """(tokens, cond cache) for a radar cube; memoised on the tensor identity so a caller that
+        invokes forward() in a loop with the same cube (the reference's sampler does, re-running
+        the 287-GFLOP encoder every NFE) encodes it once."""
+        key = (cube.data_ptr(), cube._version, tuple(cube.shape))
+        if self._cond_memo is None or self._cond_memo[0] != key:
+            tokens, cache = self._handle().encode_cond(cube)
+            self._cond_memo = (key, tokens, cache)
+        return self._cond_memo[1], self._cond_memo[2]
+
+    # -- reference API ------------------------------------------------------------------------
+    def process_radar_cond(self, radar_cube):
+        """(B,R,A,E,ch) -> (B, R'A'E', C) condition tokens (:363-407)."""
+        return self._cond(radar_cube)[0]
+
+    def forward(self, x, sigma, label_tokens=None, cond_type=None, force_fp32=False, **model_kwargs):
+        if cond_type != 'radar':
+            raise NotImplementedError("cond_type must be 'radar'")
+        h = self._handle()
+        _, cache = self._cond(label_tokens)
+        sig = torch.as_tensor(sigma, dtype=torch.float32).reshape(-1).cpu()
+        if sig.numel() not in (1, x.shape[0]):
+            raise RuntimeError("sigma must be a scalar or have one entry per sample")
+        h.set_sigmas(sig.tolist())
+        return h.denoise(x.to(torch.float32), cache, 0, per_sample=sig.numel() > 1, raw_F=False)
+
+    def round_sigma(self, sigma):
+        return torch.as_tensor(sigma)
+
+    def _sample_from(self, latents, cond, cond_type, num_steps, sigma_min, sigma_max, rho):
+        if cond_type != 'radar':
+            raise NotImplementedError("cond_type must be 'radar'")
+        h = self._handle()
+        _, cache = self._cond(cond)
+        return h.sample(latents, cache, num_steps, float(sigma_min), float(sigma_max), float(rho))
+
+    @torch.no_grad()
+    def sample(self, cond, batch_seeds=None, cond_type=None):
+        if cond is not None:
+            batch_size, device = cond.shape[0], cond.device
+            if batch_seeds is None:
+                batch_seeds = torch.arange(batch_size)
+        else:
+            raise NotImplementedError("unconditional sampling is not a reference path (cond is always the radar cube)")
+        rnd = StackedRandomGenerator(device, batch_seeds)
+        latents = rnd.randn([batch_size, self.n_latents, self.channels])
+        return edm_sampler(self, latents, cond, cond_type, randn_like=rnd.randn_like)
+
+
+# ---- factories (:452-482) --------------------------------------------------------------------
+def kl_d512_m512_l8_edm(configs=None):
+    return EDMPrecond(n_latents=512, channels=8, configs=configs)
+
+
+def kl_d512_m512_l16_edm(configs=None):
+    return EDMPrecond(n_latents=512, channels=16, configs=configs)
+
+
+def kl_d512_m512_l32_edm(configs=None):
+    return EDMPrecond(n_latents=512, channels=32, configs=configs)
+
+
+def kl_d512_m512_l4_d24_edm(configs=None):
+    return EDMPrecond(n_latents=512, channels=4, depth=24, configs=configs)
+
+
+def kl_d512_m512_l8_d24_edm(configs=None):
+    return EDMPrecond(n_latents=512, channels=8, depth=24, configs=configs)
+
+
+def kl_d512_m512_l32_d24_edm(configs=None):
+    return EDMPrecond(n_latents=512, channels=32, depth=24, configs=configs)
+
+
+def kl_d512_m512_l32_d18_edm(configs=None):
+    return EDMPrecond(n_latents=512, channels=32, depth=18, configs=configs)
+
+
+def kl_d512_m512_l32_d12_edm(configs=None):
+    return EDMPrecond(n_latents=512, channels=32, depth=12, configs=configs)

@@ -1,0 +1,74 @@
+"""Denoiser parity on a real MI355X: the HIP path (through the drop-in modules and the C-ABI)
+against the CPU oracle on identical seeded weights/inputs, and against the golden vectors
+captured from the reference.
+
+Tolerances (bf16 MFMA operands, fp32 accumulate, fp32 residual stream; the reference is fp32,
+so these are this build's stated bounds - SURVEY.md §8d):
+  one NFE, rel-L2 of F_x / D_x            <= 1.5e-2
+  18-step sampler (35 compounding NFEs)   <= 5e-2
+"""
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL_NFE = 1.5e-2
+TOL_SAMPLE = 5e-2
+
+
+def _transformer(depth, context_dim=None, seed=0):
+    from rald_amd import models_radar_generation as G, weights
+    m = G.LatentArrayTransformer(in_channels=32, t_channels=256, n_heads=8, d_head=64, depth=depth, context_dim=context_dim)
+    sd = weights.make_state_dict(weights.dit_spec(depth=depth, context_dim=context_dim, with_radar=False, prefix=""), seed)
+    m.load_state_dict(sd, strict=True)
+    return m.cuda(), sd
+
+
+def test_transformer_depth2_vs_oracle_per_sample_t():
+    from oracle import rald_oracle as O
+    from rald_amd import synth
+    m, sd = _transformer(2)
+    x = synth.latents([0, 1, 2])
+    cond = synth.cond_tokens(3)
+    t = torch.tensor([0.25, -1.0, 0.6])
+    ref = O.latent_transformer(sd, x, t, cond, depth=2, prefix="")
+    out = m(x.cuda(), t, cond=cond.cuda())
+    print("depth2 per-sample t rel_l2", rel_l2(out, ref))
+    assert rel_l2(out, ref) < TOL_NFE
+    # shared t (sampling style, B' = 1)
+    ref1 = O.latent_transformer(sd, x, t[:1], cond, depth=2, prefix="")
+    out1 = m(x.cuda(), t[:1], cond=cond.cuda())
+    assert rel_l2(out1, ref1) < TOL_NFE
+
+
+def test_transformer_full_depth_vs_reference_golden():
+    from rald_amd import synth
+    m, _ = _transformer(24)
+    g = load_golden("g2_transformer.npz")
+    out = m(synth.latents([0, 1]).cuda(), torch.tensor([0.25, -1.0]), cond=synth.cond_tokens(2).cuda())
+    print("full depth rel_l2", rel_l2(out, g["out"]))
+    assert rel_l2(out, g["out"]) < TOL_NFE
+
+
+def test_transformer_context_dim_1024_vs_reference_golden():
+    """BASELINE.json's '1024-channel radar condition' exists one level down."""
+    from rald_amd import synth
+    m, _ = _transformer(24, context_dim=1024)
+    g = load_golden("g2_transformer_ctx1024.npz")
+    out = m(synth.latents([0, 1]).cuda(), torch.tensor([0.25, -1.0]), cond=synth.cond_tokens(2, 64, 1024, seed=778).cuda())
+    print("ctx1024 rel_l2", rel_l2(out, g["out"]))
+    assert rel_l2(out, g["out"]) < TOL_NFE
+
+
+def test_batch_independence_and_b1():
+    """Samples are independent (no cross-sample op on the path): a B=1 launch must agree with the
+    matching row of a B=5 launch (tile choice differs with M, so fp32-noise, not bitwise)."""
+    from rald_amd import synth
+    m, _ = _transformer(2)
+    x = synth.latents(range(5)).cuda()
+    cond = synth.cond_tokens(5).cuda()
+    t = torch.tensor([0.1])
+    full = m(x, t, cond=cond)
+    one = m(x[3:4], t, cond=cond[3:4])
+    assert rel_l2(one, full[3:4]) < 2e-3

@@ -1,0 +1,131 @@
+"""Kernel-level parity on a real MI355X, driven through the C-ABI (rald_op_*).  Each kernel is
+compared with a plain fp32 PyTorch statement of the same op.  Exact-integer cases pin the MFMA
+fragment / accumulator layouts bit-for-bit (an asymmetric B catches a transposed C-write)."""
+import math
+
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    from rald_amd import _handles
+    return _handles
+
+
+def _ints(shape, lo, hi, seed):
+    g = torch.Generator("cpu").manual_seed(seed)
+    return torch.randint(lo, hi + 1, shape, generator=g).float()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (64, 64, 128), (256, 384, 512), (512, 512, 512),
+                                   (200, 132, 64), (8192, 512, 512), (1024, 4096, 512), (300, 1000, 1024)])
+def test_gemm_exact_integers(H, M, N, K):
+    A = _ints((M, K), -3, 3, 1).cuda()
+    B = (_ints((N, K), -2, 2, 2) + (torch.arange(N) % 3 == 0).float()[:, None]).cuda()   # asymmetric
+    ref = A @ B.t()
+    out = H.op_gemm_nt(A.bfloat16(), B.bfloat16(), epilogue=1)
+    assert torch.equal(out, ref)
+    out16 = H.op_gemm_nt(A.bfloat16(), B.bfloat16(), epilogue=0)
+    assert torch.equal(out16.float(), ref.bfloat16().float())
+
+
+def test_gemm_batched_and_bias_and_alpha(H):
+    A = torch.randn(512, 512, device="cuda").bfloat16()            # shared "weights" as the A operand
+    Bm = torch.randn(3, 96, 512, device="cuda").bfloat16()
+    bias = torch.randn(96, device="cuda")
+    out = H.op_gemm_nt(A, Bm, bias=bias, epilogue=1, alpha=0.5)
+    ref = 0.5 * torch.einsum("mk,bnk->bmn", A.float(), Bm.float()) + bias
+    assert rel_l2(out, ref) < 2e-6
+
+
+@pytest.mark.parametrize("M", [512, 4096 * 8])
+def test_gemm_residual_epilogue(H, M):
+    A = torch.randn(M, 2048, device="cuda").bfloat16()
+    W = (torch.randn(512, 2048, device="cuda") / 45).bfloat16()
+    bias = torch.randn(512, device="cuda")
+    x = torch.randn(M, 512, device="cuda")
+    ref = x + A.float() @ W.float().t() + bias
+    H.op_gemm_nt(A, W, bias=bias, epilogue=2, C_inout=x)
+    assert rel_l2(x, ref) < 2e-6
+
+
+@pytest.mark.parametrize("M", [512, 16384])
+def test_gemm_geglu_epilogue(H, M):
+    inner = 2048
+    A = torch.randn(M, 512, device="cuda").bfloat16()
+    W = (torch.randn(2 * inner, 512, device="cuda") / 22).bfloat16()
+    bias = torch.randn(2 * inner, device="cuda") * 0.1
+    c = torch.arange(inner)
+    rowmap = torch.cat([32 * (c // 16) + c % 16, 32 * (c // 16) + 16 + c % 16]).cuda()
+    Wp = torch.empty_like(W); Wp[rowmap] = W
+    bp = torch.empty_like(bias); bp[rowmap] = bias
+    out = H.op_gemm_nt(A, Wp, bias=bp, epilogue=3)
+    y = A.float() @ W.float().t() + bias
+    ref = y[:, :inner] * torch.nn.functional.gelu(y[:, inner:])
+    assert out.shape == (M, inner)
+    assert rel_l2(out, ref) < 4e-3          # bf16 output rounding (2^-9 relative per element)
+
+
+@pytest.mark.parametrize("D", [256, 512, 1024])
+def test_layernorm_plain_and_modulated(H, D):
+    M = 1000
+    x = torch.randn(M, D, device="cuda") * 3 + 1
+    g = torch.randn(D, device="cuda"); b = torch.randn(D, device="cuda")
+    out = H.op_layernorm(x, g, b)
+    ref = torch.nn.functional.layer_norm(x, (D,), g, b)
+    assert rel_l2(out, ref) < 4e-3
+    # AdaLN: per-group (sample) modulation rows, (1+scale), rows_per_group = 250
+    mod = torch.randn(4, 2 * D, device="cuda")
+    out = H.op_layernorm(x, mod, mod[:, D:], gstride=2 * D, rows_per_group=250, add_one=1.0)
+    grp = torch.arange(M, device="cuda") // 250
+    ref = torch.nn.functional.layer_norm(x, (D,)) * (1 + mod[grp, :D]) + mod[grp, D:]
+    assert rel_l2(out, ref) < 4e-3
+
+
+def _attn_ref(q, k, v, heads, scale):
+    B, nq, HD = q.shape
+    d = HD // heads
+    qh = q.float().view(B, nq, heads, d).transpose(1, 2)
+    kh = k.float().view(B, -1, heads, d).transpose(1, 2)
+    vh = v.float().view(B, -1, heads, d).transpose(1, 2)
+    p = (qh @ kh.transpose(-1, -2) * scale).softmax(-1)
+    return (p @ vh).transpose(1, 2).reshape(B, nq, HD)
+
+
+@pytest.mark.parametrize("B,nq,nk,heads", [(2, 512, 512, 8), (1, 128, 64, 8), (3, 512, 64, 8), (1, 512, 1000, 8), (2, 96, 10000, 2)])
+def test_attention_d64(H, B, nq, nk, heads):
+    HD = heads * 64
+    nkp = (nk + 31) // 32 * 32
+    g = torch.Generator("cpu").manual_seed(3)
+    q = torch.randn(B, nq, HD, generator=g).cuda().bfloat16()
+    k = torch.zeros(B, nkp, HD).cuda().bfloat16()
+    k[:, :nk] = torch.randn(B, nk, HD, generator=g).cuda().bfloat16()
+    v = torch.randn(B, nk, HD, generator=g).cuda().bfloat16()
+    k[:, nk:] = 7.0                                   # garbage in the key pad must be masked out
+    vt = torch.zeros(B, HD, nkp, device="cuda", dtype=torch.bfloat16)
+    vt[:, :, :nk] = v.transpose(1, 2)
+    scale = 1.0 / math.sqrt(64)
+    out = H.op_attention(q, k, vt, nk, heads, scale)
+    ref = _attn_ref(q, k[:, :nk], v, heads, scale)
+    assert rel_l2(out, ref) < 6e-3                     # P and O are rounded to bf16
+
+
+def test_attention_exact_one_hot(H):
+    """Scores engineered so softmax is (numerically) one-hot: O must reproduce the selected V
+    rows exactly - pins the key<->accumulator-row permutation of the P.V MFMA."""
+    B, nq, nk, heads = 1, 64, 96, 1
+    q = torch.zeros(B, nq, 64)
+    k = torch.full((B, nk, 64), -16.0)
+    sel = (torch.arange(nq) * 7 + 3) % nk              # distinct keys (7 is coprime with 96)
+    for i in range(nq):
+        q[0, i, i] = 16.0
+        k[0, sel[i], i] = 16.0                         # query i matches key sel[i]: score 256 vs -256
+    v = _ints((B, nk, 64), -8, 8, 5)
+    vt = v.transpose(1, 2).contiguous()
+    out = H.op_attention(q.cuda().bfloat16(), k.cuda().bfloat16(), vt.cuda().bfloat16(), nk, heads, 1.0)
+    assert torch.equal(out.float().cpu()[0], v[0, sel])
