@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py - BASELINE.json's headline metric on MI355X.
+
+metric   : denoising steps/sec (whole node) = sample*NFE per second: one forward of the
+           24-block radar-conditioned denoiser for one sample, condition tokens cached
+           (SURVEY.md §8d).  One bench "step" = one NFE over a batch of B samples per GPU.
+workload : BASELINE.json configs[2] - models_radar_generation DiT denoiser
+           (kl_d512_m512_l32_d24_edm) on random 512x32 latents + synthetic radar-spectrum
+           condition tokens [B,64,512]; seeded random weights (no checkpoints exist offline).
+extras   : AE encode / decode latency (configs[1]) and the 18-step sampler rate are reported
+           as extra keys of the same JSON line when --extras is on (default at N=1).
+
+Multi-GPU (driver launches torchrun, one rank per GPU): samples are independent, so the batch
+is sharded across ranks with NO data-path collective ("weak" scaling: B per GPU is fixed);
+the only communication is the barrier + MAX-reduce of the elapsed time (RCCL).
+
+  python bench.py --gpus N --steps K --warmup W [--batch B]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_NFE = 132.18          # SURVEY.md §8d / BASELINE.md §3 (multiply-add = 2 FLOP)
+PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip table)
+
+
+def dist_setup(n_gpus):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    return world, rank, local
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(val, world):
+    if world == 1:
+        return val
+    import torch.distributed as dist
+    t = torch.tensor([val], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def build_denoiser(depth=24):
+    from rald_amd import models_radar_generation as G, weights
+    m = G.LatentArrayTransformer(in_channels=32, t_channels=256, n_heads=8, d_head=64, depth=depth)
+    sd = weights.make_state_dict(weights.dit_spec(depth=depth, with_radar=False, prefix="model."), seed=0)
+    m.load_state_dict({k[len("model."):]: v for k, v in sd.items()})
+    return m.cuda(), sd
+
+
+def cpu_baseline_nfe(sd, depth, seconds_budget=20.0):
+    """The oracle (fp32 PyTorch restatement of the reference path, oracle/rald_oracle.py) timed on
+    this box's host cores: a bounded sample of the same workload (B=2 NFEs)."""
+    from oracle import rald_oracle as O
+    from rald_amd import synth
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B = 2
+    x = synth.latents(range(B))
+    cond = synth.cond_tokens(B)
+    t = torch.tensor([0.0])
+    with torch.no_grad():
+        O.latent_transformer(sd, x, t, cond, depth=depth)            # warm-up
+        reps, t0 = 0, time.perf_counter()
+        while reps < 3 or (time.perf_counter() - t0 < seconds_budget / 2 and reps < 12):
+            O.latent_transformer(sd, x, t, cond, depth=depth)
+            reps += 1
+        dt = time.perf_counter() - t0
+    return {"value": B * reps / dt, "unit": "sample*NFE/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} NFEs of the fp32 oracle at B={B} (same weights/shapes), torch CPU {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="samples per GPU per NFE")
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world, rank, local = dist_setup(args.gpus)
+    from rald_amd import synth
+    depth = 24
+    m, sd = build_denoiser(depth)
+    h = m._handle(512, 64)
+    B = args.batch
+    # each rank owns its own shard of the global batch: samples rank*B .. rank*B+B-1
+    seeds = range(rank * B, rank * B + B)
+    x = synth.latents(seeds).cuda()
+    cond = synth.cond_tokens(B, seed=777 + rank).cuda()
+    cache = h.encode_cond_tokens(cond)
+    h.set_sigmas([1.0])
+    torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        h.denoise(x, cache, 0)
+    barrier(world)
+    h.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        h.denoise(x, cache, 0)
+    barrier(world)
+    elapsed = time.perf_counter() - t0
+    ff1_ms, ff1_launches = h.profile_end()
+    elapsed = max_over_ranks(elapsed, world)
+
+    total_units = world * B * args.steps
+    value = total_units / elapsed
+    # dominant kernel: the FF1 GEGLU GEMM [B*512, 512] x [512, 4096] (40% of an NFE's FLOPs)
+    ff1_flops = 2.0 * (B * 512) * 4096 * 512
+    avg_s = (ff1_ms / max(ff1_launches, 1)) * 1e-3
+    achieved = ff1_flops / avg_s / 1e12 if avg_s > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(f"ff1_geglu_gemm_B{B}")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "denoising steps/sec (whole node)", "value": value, "unit": "sample*NFE/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "configs[2]: kl_d512_m512_l32_d24_edm denoiser NFE, 512x32 latents, 64x512 radar condition tokens (cached)",
+                   "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"batch-sharded x{world}, no data-path collective",
+                   "weights": "seeded random (rald_amd.weights, seed 0)"},
+        "whole_path_tflops": value * GFLOP_PER_NFE / 1e3,
+        "heun_steps_per_s": value * 18.0 / 35.0, "samples_per_s_18step": value / 35.0,
+        "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<128,128,GEGLU> (FF1: [B*512,512]x[512,4096], GEGLU epilogue)",
+                     "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+                     "launches_timed": ff1_launches, "avg_launch_us": avg_s * 1e6,
+                     "algorithmic_flop_per_launch": ff1_flops},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_nfe(sd, depth)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        try:
+            from rald_amd import bench_extras
+            out.update(bench_extras.run(h))
+        except Exception as e:  # extras never invalidate the headline line
+            out["extras_error"] = repr(e)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

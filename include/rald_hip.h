@@ -88,6 +88,12 @@ int rald_dit_denoise(rald_dit* h, const float* x, int32_t batch, int32_t sigma_r
 int rald_dit_sample(rald_dit* h, const float* latents, int32_t batch, const void* cond_cache, int32_t num_steps,
                     float sigma_min, float sigma_max, float rho, float* out, void* stream);
 
+/* Live timing of the dominant kernel (the FF1 GEGLU GEMM, FeedForward :88-117): between begin
+ * and end every launch of it inside rald_dit_denoise is bracketed by HIP events recorded on the
+ * launch stream (up to 4096 launches); end synchronises those events and returns their sum. */
+int rald_dit_profile_begin(rald_dit* h);
+int rald_dit_profile_end(rald_dit* h, double* total_ms, int32_t* launches);
+
 /* ------------------------------------------------------------------------------------------
  * Kernel-level entry points (what the parity tests and microbenchmarks drive directly)
  * ---------------------------------------------------------------------------------------- */

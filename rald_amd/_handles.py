@@ -93,6 +93,14 @@ class DitHandle:
                                      C.c_void_p(_ptr(cache)), C.c_void_p(_ptr(out)), int(raw_F), C.c_void_p(_stream())))
         return out
 
+    def profile_begin(self) -> None:
+        check(lib().rald_dit_profile_begin(self._h))
+
+    def profile_end(self):
+        ms, n = C.c_double(0), C.c_int32(0)
+        check(lib().rald_dit_profile_end(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def sample(self, latents: torch.Tensor, cache: torch.Tensor, num_steps: int = 18, sigma_min: float = 0.002,
                sigma_max: float = 80.0, rho: float = 7.0) -> torch.Tensor:
         _need_cuda(latents, "latents")

@@ -48,6 +48,8 @@ SIGNATURES = {
     "rald_dit_encode_cond": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "rald_dit_denoise": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "rald_dit_sample": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_float, c_float, c_float, c_void_p, c_void_p]),
+    "rald_dit_profile_begin": (c_int, [c_void_p]),
+    "rald_dit_profile_end": (c_int, [c_void_p, C.POINTER(C.c_double), C.POINTER(c_int)]),
     "rald_op_gemm_nt": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p,
                                 c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "rald_op_layernorm": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_i64, c_int, c_float, c_float, c_void_p]),

@@ -62,6 +62,15 @@ int rald_dit_sample(rald_dit* h, const float* latents, int32_t batch, const void
     return h->impl.sample(latents, batch, cond_cache, num_steps, sigma_min, sigma_max, rho, out, (hipStream_t)stream);
 }
 
+int rald_dit_profile_begin(rald_dit* h) { RALD_CHECK(h, "null handle"); return h->impl.profile_begin(); }
+int rald_dit_profile_end(rald_dit* h, double* total_ms, int32_t* launches) {
+    RALD_CHECK(h && total_ms && launches, "rald_dit_profile_end: null argument");
+    int n = 0;
+    int rc = h->impl.profile_end(total_ms, &n);
+    *launches = n;
+    return rc;
+}
+
 // ---- kernel-level entry points -----------------------------------------------------------------
 int rald_op_gemm_nt(const void* A, int64_t lda, int64_t strideA, const void* B, int64_t ldb, int64_t strideB,
                     void* C, int64_t ldc, int64_t strideC, const float* bias, int32_t M, int32_t N, int32_t K,

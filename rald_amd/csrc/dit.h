@@ -77,6 +77,14 @@ struct Dit {
     float *ws_x = nullptr, *ws_xcur = nullptr, *ws_xeul = nullptr, *ws_den = nullptr, *ws_dcur = nullptr;
     bf16 *ws_h = nullptr, *ws_qk = nullptr, *ws_vt = nullptr, *ws_o = nullptr, *ws_q2 = nullptr, *ws_g = nullptr, *ws_tok = nullptr;
 
+    // live timing of the dominant kernel (the FF1 GEGLU GEMM) with HIP events on the launch stream
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;
+    int prof_used = 0;
+    int profile_begin();
+    int profile_end(double* total_ms, int* launches);
+    ~Dit();
+
     int create();
     int load_weight(const std::string& name, const float* data, int64_t nelem);
     int finalize();

@@ -20,20 +20,20 @@ void* DeviceArena::alloc(size_t bytes, bool zero) {
     void* p = nullptr;
     if (bytes == 0) bytes = 16;
     if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
-    if (zero) hipMemset(p, 0, bytes);
+    if (zero) (void)hipMemset(p, 0, bytes);
     ptrs.push_back(p);
     return p;
 }
 void DeviceArena::release(void* p) {
     for (size_t i = 0; i < ptrs.size(); ++i)
         if (ptrs[i] == p) {
-            hipFree(p);
+            (void)hipFree(p);
             ptrs.erase(ptrs.begin() + i);
             return;
         }
 }
 DeviceArena::~DeviceArena() {
-    for (void* p : ptrs) hipFree(p);
+    for (void* p : ptrs) (void)hipFree(p);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -48,7 +48,7 @@ __global__ void pack_rows_f32_kernel(const float* __restrict__ src, float* __res
 
 int Stager::ensure(size_t bytes) {
     if (bytes <= cap) return 0;
-    if (buf) hipFree(buf);
+    if (buf) (void)hipFree(buf);
     buf = nullptr;
     cap = 0;
     RALD_HIP(hipMalloc(&buf, bytes));
@@ -56,7 +56,7 @@ int Stager::ensure(size_t bytes) {
     return 0;
 }
 Stager::~Stager() {
-    if (buf) hipFree(buf);
+    if (buf) (void)hipFree(buf);
 }
 int Stager::fetch(const float* data, int64_t nelem) {
     RALD_TRY(ensure((size_t)nelem * 4));
@@ -392,12 +392,42 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
         // ---- x += ff(norm3(x, t))                                                   (:168)
         RALD_TRY(layernorm_mod(ws_x, ws_h, M, D, m3, m3 + D, gstride, NL, 1.0f, 1e-5f, st));
         GemmArgs f1 = gemm_args(ws_h, D, l.w_ff1, D, ws_g, 4 * D, l.b_ff1, M, 8 * D, D);
+        const bool timed = prof_on && prof_used + 2 <= (int)prof_ev.size();
+        if (timed) RALD_HIP(hipEventRecord(prof_ev[prof_used], st));
         RALD_TRY(gemm_nt(f1, EPI_GEGLU, st));
+        if (timed) { RALD_HIP(hipEventRecord(prof_ev[prof_used + 1], st)); prof_used += 2; }
         GemmArgs f2 = gemm_args(ws_g, 4 * D, l.w_ff2, 4 * D, ws_x, D, l.b_ff2, M, D, 4 * D);
         RALD_TRY(gemm_nt(f2, EPI_RESID, st));
     }
     RALD_TRY(final_norm_proj(ws_x, norm_g, norm_b, w_out, x, out, M, D, C, coef, cstride, NL, st));
     return 0;
+}
+
+int Dit::profile_begin() {
+    if (prof_ev.empty()) {
+        prof_ev.resize(2 * 4096);
+        for (auto& e : prof_ev) RALD_HIP(hipEventCreate(&e));
+    }
+    prof_used = 0;
+    prof_on = true;
+    return 0;
+}
+int Dit::profile_end(double* total_ms, int* launches) {
+    prof_on = false;
+    double tot = 0.0;
+    for (int i = 0; i + 1 < prof_used; i += 2) {
+        RALD_HIP(hipEventSynchronize(prof_ev[i + 1]));
+        float ms = 0.f;
+        RALD_HIP(hipEventElapsedTime(&ms, prof_ev[i], prof_ev[i + 1]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = prof_used / 2;
+    prof_used = 0;
+    return 0;
+}
+Dit::~Dit() {
+    for (auto& e : prof_ev) (void)hipEventDestroy(e);
 }
 
 int Dit::sample(const float* latents, int B, const void* cache, int num_steps, float smin, float smax, float rho,

@@ -203,7 +203,7 @@ int gemm_nt(const GemmArgs& a, int epi, hipStream_t st) {
     }
     // 128x128 tiles when they fill the chip; 64x64 tiles for the small-M (batch-1) regime.
     const int64_t wg128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) * a.batch;
-    if (wg128 >= 192 || epi == EPI_GEGLU && a.N % 64 != 0) return launch_tile<128, 128>(a, epi, st);
+    if (wg128 >= 192) return launch_tile<128, 128>(a, epi, st);
     return launch_tile<64, 64>(a, epi, st);
 }
 
