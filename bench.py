@@ -31,6 +31,11 @@ GFLOP_PER_NFE = 132.18          # SURVEY.md §8d / BASELINE.md §3 (multiply-add
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip table)
 
 
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
 def dist_setup(n_gpus):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -74,16 +79,24 @@ def cpu_baseline_nfe(sd, depth, seconds_budget=20.0):
     this box's host cores: a bounded sample of the same workload (B=2 NFEs)."""
     from oracle import rald_oracle as O
     from rald_amd import synth
-    cores = os.cpu_count() or 1
+    # the GPU box gives a 1-GPU job a 16-core share; os.cpu_count() reports the whole host
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
     torch.set_num_threads(cores)
     B = 2
     x = synth.latents(range(B))
     cond = synth.cond_tokens(B)
     t = torch.tensor([0.0])
     with torch.no_grad():
+        tw = time.perf_counter()
         O.latent_transformer(sd, x, t, cond, depth=depth)            # warm-up
+        tw = time.perf_counter() - tw
+        log(f"cpu baseline: warm-up NFE pair took {tw:.2f}s on {cores} threads")
         reps, t0 = 0, time.perf_counter()
-        while reps < 3 or (time.perf_counter() - t0 < seconds_budget / 2 and reps < 12):
+        while reps < 2 or (time.perf_counter() - t0 < seconds_budget and reps < 12):
             O.latent_transformer(sd, x, t, cond, depth=depth)
             reps += 1
         dt = time.perf_counter() - t0
@@ -104,6 +117,7 @@ def main():
     world, rank, local = dist_setup(args.gpus)
     from rald_amd import synth
     depth = 24
+    log("building denoiser + packing weights")
     m, sd = build_denoiser(depth)
     h = m._handle(512, 64)
     B = args.batch
@@ -115,6 +129,7 @@ def main():
     h.set_sigmas([1.0])
     torch.cuda.synchronize()
 
+    log(f"warm-up {args.warmup} + timed {args.steps} NFEs at B={B}/GPU on {world} GPU(s)")
     for _ in range(args.warmup):
         h.denoise(x, cache, 0)
     barrier(world)
@@ -157,11 +172,13 @@ def main():
                      "launches_timed": ff1_launches, "avg_launch_us": avg_s * 1e6,
                      "algorithmic_flop_per_launch": ff1_flops},
     }
+    log(f"GPU: {value:.1f} sample*NFE/s, FF1 kernel {achieved:.0f} TFLOP/s over {ff1_launches} launches")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_nfe(sd, depth)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0 and world == 1 and not args.no_extras:
+        log("extras: sampler / AE timings")
         try:
             from rald_amd import bench_extras
             out.update(bench_extras.run(h))
