@@ -95,6 +95,41 @@ int rald_dit_profile_begin(rald_dit* h);
 int rald_dit_profile_end(rald_dit* h, double* total_ms, int32_t* launches);
 
 /* ------------------------------------------------------------------------------------------
+ * Set-latent autoencoder: KLAutoEncoder, query_type='mix'  (model/models_ae.py:284-432)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct rald_ae rald_ae;
+typedef struct rald_ae_config {
+    int32_t dim;          /* 512 (tiny config: 256)      create_autoencoder(dim=..) :434   */
+    int32_t num_latents;  /* 512 (tiny: 128)             M                                  */
+    int32_t latent_dim;   /* 32                          latent_dim                         */
+    int32_t depth;        /* 24 (hard-coded :449)                                           */
+    int32_t heads;        /* 8  (hard-coded :455)                                           */
+    int32_t dim_head;     /* 64 (hard-coded :456)                                           */
+    int32_t num_inputs;   /* P: encode asserts pc.shape[1] == num_inputs (:354)             */
+} rald_ae_config;
+
+int rald_ae_create(const rald_ae_config* cfg, rald_ae** out);
+void rald_ae_destroy(rald_ae* h);
+int rald_ae_load_weight(rald_ae* h, const char* name, const float* data, int64_t nelem);
+int rald_ae_finalize(rald_ae* h);
+/* KLAutoEncoder.encode (:351-405): pc [B,P,3]; eps [B,M,latent_dim] = the posterior noise
+ * (the reference draws it with torch.randn on the CPU global RNG, :153 - the caller passes it so
+ * results are reproducible); outputs z [B,M,L], kl [B], and optionally mean / logvar [B,M,L]
+ * (NULL to skip). */
+int rald_ae_encode(rald_ae* h, const float* pc, int32_t batch, const float* eps, float* out_mean, float* out_logvar,
+                   float* out_z, float* out_kl, void* stream);
+/* decode (:408-424) split at its query-independent part: the latent stack (proj + depth x
+ * [self-attention, GEGLU FF]) and the decoder context are computed ONCE per z into `ctx`
+ * (rald_ae_ctx_bytes bytes, 16-byte aligned); any number of query sets can then be decoded
+ * against it (the reference recomputes the 116-GFLOP stack for each of its <=4 decode calls per
+ * sample, engine_generation.py:204, :275, :300). */
+int64_t rald_ae_ctx_bytes(const rald_ae* h, int32_t batch);
+int rald_ae_decode_latents(rald_ae* h, const float* z, int32_t batch, void* ctx, void* stream);
+/* queries [B,Q,3] -> occupancy logits [B,Q] (the reference returns [B,Q,1]; occupied iff > 0) */
+int rald_ae_decode_queries(rald_ae* h, const void* ctx, const float* queries, int32_t batch, int64_t n_queries,
+                           float* out_logits, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Kernel-level entry points (what the parity tests and microbenchmarks drive directly)
  * ---------------------------------------------------------------------------------------- */
 /* C[b][m][n] = alpha * sum_k A[b][m][k]*B[b][n][k] (+bias[n]); A,B bf16 (K contiguous).

@@ -153,3 +153,58 @@ def op_attention(Q: torch.Tensor, K: torch.Tensor, Vt: torch.Tensor, nk: int, he
                                   C.c_void_p(_ptr(Vt)), Vt.stride(1), Vt.stride(0), C.c_void_p(_ptr(O)), O.stride(1), O.stride(0),
                                   nq, nk, K.shape[1], heads, Bn, scale, C.c_void_p(_stream())))
     return O
+
+
+class AeHandle:
+    """rald_ae*: encode / decode_latents / decode_queries of the set-latent autoencoder."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        check(lib().rald_ae_create(C.byref(cfg), C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().rald_ae_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def load(self, named) -> None:
+        for name, t in named:
+            t = _f32c(t)
+            check(lib().rald_ae_load_weight(self._h, name.encode(), C.c_void_p(_ptr(t)), t.numel()))
+        check(lib().rald_ae_finalize(self._h))
+
+    def encode(self, pc: torch.Tensor, eps: torch.Tensor, want_moments: bool = False):
+        _need_cuda(pc, "point cloud")
+        pc, eps = _f32c(pc), _f32c(eps).to(pc.device)
+        B = pc.shape[0]
+        M, L = self.cfg.num_latents, self.cfg.latent_dim
+        if pc.shape[1] != self.cfg.num_inputs:
+            raise AssertionError(f"encode expects {self.cfg.num_inputs} points, got {pc.shape[1]}")   # models_ae.py:354
+        z = torch.empty(B, M, L, device=pc.device, dtype=torch.float32)
+        kl = torch.empty(B, device=pc.device, dtype=torch.float32)
+        mean = torch.empty_like(z) if want_moments else None
+        logvar = torch.empty_like(z) if want_moments else None
+        check(lib().rald_ae_encode(self._h, C.c_void_p(_ptr(pc)), B, C.c_void_p(_ptr(eps)),
+                                   C.c_void_p(_ptr(mean) if want_moments else 0), C.c_void_p(_ptr(logvar) if want_moments else 0),
+                                   C.c_void_p(_ptr(z)), C.c_void_p(_ptr(kl)), C.c_void_p(_stream())))
+        return (kl, z, mean, logvar) if want_moments else (kl, z)
+
+    def decode_latents(self, z: torch.Tensor) -> torch.Tensor:
+        _need_cuda(z, "latents")
+        z = _f32c(z)
+        ctx = torch.empty(lib().rald_ae_ctx_bytes(self._h, z.shape[0]), dtype=torch.uint8, device=z.device)
+        check(lib().rald_ae_decode_latents(self._h, C.c_void_p(_ptr(z)), z.shape[0], C.c_void_p(_ptr(ctx)), C.c_void_p(_stream())))
+        return ctx
+
+    def decode_queries(self, ctx: torch.Tensor, queries: torch.Tensor) -> torch.Tensor:
+        _need_cuda(queries, "queries")
+        queries = _f32c(queries)
+        B, Q, _ = queries.shape
+        out = torch.empty(B, Q, device=queries.device, dtype=torch.float32)
+        check(lib().rald_ae_decode_queries(self._h, C.c_void_p(_ptr(ctx)), C.c_void_p(_ptr(queries)), B, Q, C.c_void_p(_ptr(out)),
+                                           C.c_void_p(_stream())))
+        return out

@@ -50,6 +50,14 @@ SIGNATURES = {
     "rald_dit_sample": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_float, c_float, c_float, c_void_p, c_void_p]),
     "rald_dit_profile_begin": (c_int, [c_void_p]),
     "rald_dit_profile_end": (c_int, [c_void_p, C.POINTER(C.c_double), C.POINTER(c_int)]),
+    "rald_ae_create": (c_int, [C.POINTER(AeConfig), C.POINTER(c_void_p)]),
+    "rald_ae_destroy": (None, [c_void_p]),
+    "rald_ae_load_weight": (c_int, [c_void_p, c_char_p, c_void_p, c_i64]),
+    "rald_ae_finalize": (c_int, [c_void_p]),
+    "rald_ae_encode": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rald_ae_ctx_bytes": (c_i64, [c_void_p, c_int]),
+    "rald_ae_decode_latents": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "rald_ae_decode_queries": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_void_p, c_void_p]),
     "rald_op_gemm_nt": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p,
                                 c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "rald_op_layernorm": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_i64, c_int, c_float, c_float, c_void_p]),

@@ -1,0 +1,64 @@
+// Host-side state of the autoencoder handle (see ae.hip).
+#pragma once
+#include "dit.h"
+
+namespace rald {
+
+struct Ae {
+    rald_ae_config cfg;
+    int d = 512;     // model dim
+    int I = 512;     // heads*dim_head of the multi-head blocks
+    static constexpr int64_t QUERY_CHUNK = 131072;
+    DeviceArena arena;
+    Stager stager;
+    struct AttnW { bf16 *w_q = nullptr, *w_k = nullptr, *w_v = nullptr, *w_o = nullptr; float *b_o = nullptr, *ng = nullptr, *nb = nullptr, *cg = nullptr, *cb = nullptr; };
+    struct FfW { bf16 *w1 = nullptr, *w2 = nullptr; float *b1 = nullptr, *b2 = nullptr, *ng = nullptr, *nb = nullptr; };
+    struct Layer { bf16 *w_qk = nullptr, *w_v = nullptr, *w_o = nullptr; float *b_o = nullptr, *ng = nullptr, *nb = nullptr; FfW ff; };
+    AttnW cross, mix, dec;
+    FfW cross_ff;
+    std::vector<Layer> layers;
+    float *basis = nullptr, *b_pe = nullptr, *s_lat = nullptr, *d_lat = nullptr, *b_qp = nullptr, *w_proj = nullptr, *b_proj = nullptr,
+          *b_ml = nullptr, *w_fold = nullptr;
+    bf16 *w_pe = nullptr, *q1 = nullptr, *w_qp = nullptr, *w_ml = nullptr, *wq_dec_t = nullptr;
+    int* d_geglu_map = nullptr;
+    float c0 = 0.f;
+    std::vector<float> h_dec_wq, h_dec_wkv, h_dec_wo, h_dec_bo, h_out_w, h_out_b;
+    std::set<std::string> expected, loaded;
+    bool finalized = false;
+    // encode workspace
+    int enc_batch = 0;
+    bf16 *e_feat = nullptr, *e_emb16 = nullptr, *e_embn16 = nullptr, *e_k = nullptr, *e_vt = nullptr, *e_o = nullptr, *e_xq = nullptr,
+         *e_h = nullptr, *e_q2 = nullptr, *e_p = nullptr, *e_g = nullptr;
+    float *e_emb32 = nullptr, *e_dq = nullptr, *e_x = nullptr, *e_s = nullptr, *e_ml = nullptr;
+    std::vector<void**> enc_ptrs() {
+        return {(void**)&e_feat, (void**)&e_emb16, (void**)&e_embn16, (void**)&e_k, (void**)&e_vt, (void**)&e_o, (void**)&e_xq, (void**)&e_h,
+                (void**)&e_q2, (void**)&e_p, (void**)&e_g, (void**)&e_emb32, (void**)&e_dq, (void**)&e_x, (void**)&e_s, (void**)&e_ml};
+    }
+    // latent-stack workspace
+    int dec_batch = 0;
+    float* x_x = nullptr;
+    bf16 *x_h = nullptr, *x_qk = nullptr, *x_vt = nullptr, *x_o = nullptr, *x_g = nullptr, *x_kd = nullptr;
+    std::vector<void**> dec_ptrs() {
+        return {(void**)&x_x, (void**)&x_h, (void**)&x_qk, (void**)&x_vt, (void**)&x_o, (void**)&x_g, (void**)&x_kd};
+    }
+    // query workspace (one chunk)
+    int64_t q_rows = 0;
+    bf16 *y_feat = nullptr, *y_qn = nullptr;
+    float *y_qe = nullptr, *y_s = nullptr;
+    std::vector<void**> qry_ptrs() { return {(void**)&y_feat, (void**)&y_qn, (void**)&y_qe, (void**)&y_s}; }
+
+    int create();
+    int load_attn(AttnW& a, int inner, const std::string& t, const float* data, int64_t nelem, bool* handled);
+    int load_ff(FfW& f, const std::string& t, const float* data, int64_t nelem, bool* handled);
+    int load_weight(const std::string& name, const float* data, int64_t nelem);
+    int finalize();
+    int reserve_encode(int B);
+    int reserve_decode(int B);
+    int reserve_queries(int64_t rows);
+    int encode(const float* pc, int B, const float* eps, float* mean_o, float* logvar_o, float* z, float* kl, hipStream_t st);
+    int64_t ctx_bytes(int B) const;
+    int decode_latents(const float* z, int B, void* ctx, hipStream_t st);
+    int decode_queries(const void* ctx, const float* q, int B, int64_t Q, float* out, hipStream_t st);
+};
+
+}  // namespace rald

@@ -1,0 +1,444 @@
+// Set-latent autoencoder handle (KLAutoEncoder, query_type='mix'; model/models_ae.py:284-432).
+//
+//   encode          :351-405   PointEmbed -> mix query (8x64-head attention over the P points,
+//                              no residual) -> query_proj -> 1-head d=dim cross-attention over the
+//                              points + residual -> GEGLU FF + residual -> mean/logvar -> posterior
+//   decode_latents  :410-414   proj -> depth x (self-attention, GEGLU FF), then the decoder context
+//   decode_queries  :417-424   PointEmbed(queries) -> 1-head cross-attention over the latents -> Linear(dim,1)
+//
+// Decode is algebraically folded (exact in real arithmetic; the reference has no nonlinearity
+// between these Linears):  S = LN(qe).Wq^T.K^T = LN(qe).G^T with G = K.Wq per sample, and
+// to_outputs(to_out(P.V)) = P.u + c with u = LN_ctx(x).(Wv^T.Wo^T.w_out): per query one K=dim
+// GEMM row against G plus a softmax-weighted dot with u - 0.59 MFLOP instead of 2.15 MFLOP and
+// no [Q,dim] intermediate beyond the embedding.
+#include "ae.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace rald {
+
+static int fetch_host(std::vector<float>& dst, const float* data, int64_t n) {
+    dst.resize((size_t)n);
+    RALD_HIP(hipMemcpy(dst.data(), data, (size_t)n * 4, hipMemcpyDefault));
+    return 0;
+}
+
+int Ae::create() {
+    const auto& c = cfg;
+    d = c.dim;
+    I = c.heads * c.dim_head;
+    RALD_CHECK(c.dim_head == 64 && I == 512, "ae: heads*dim_head must be 8x64 (create_autoencoder hard-codes it, models_ae.py:447-458)");
+    RALD_CHECK(d == 256 || d == 512, "ae: dim must be 256 or 512");
+    RALD_CHECK(c.num_latents > 0 && c.num_latents % 32 == 0, "ae: num_latents must be a multiple of 32");
+    RALD_CHECK(c.latent_dim >= 1 && c.latent_dim <= 64 && (2 * c.latent_dim) % 4 == 0, "ae: latent_dim must be in [2,64] and even");
+    RALD_CHECK(c.depth >= 1 && c.depth <= 256, "ae: bad depth");
+    RALD_CHECK(c.num_inputs >= 32, "ae: num_inputs too small");
+    const int M = c.num_latents, L = c.latent_dim;
+    auto B16 = [&](size_t n) { return (bf16*)arena.alloc(n * 2, true); };
+    auto F32 = [&](size_t n) { return (float*)arena.alloc(n * 4, true); };
+    basis = F32(72);
+    w_pe = B16((size_t)d * 64);
+    b_pe = F32(d);
+    auto mk_attn = [&](AttnW& a, int inner, bool ctx_norm) {
+        a.w_q = B16((size_t)inner * d); a.w_k = B16((size_t)inner * d); a.w_v = B16((size_t)inner * d);
+        a.w_o = B16((size_t)d * inner); a.b_o = F32(d); a.ng = F32(d); a.nb = F32(d);
+        if (ctx_norm) { a.cg = F32(d); a.cb = F32(d); }
+    };
+    auto mk_ff = [&](FfW& f) {
+        f.w1 = B16((size_t)8 * d * d); f.b1 = F32((size_t)8 * d); f.w2 = B16((size_t)d * 4 * d); f.b2 = F32(d);
+        f.ng = F32(d); f.nb = F32(d);
+    };
+    mk_attn(cross, d, true);
+    mk_ff(cross_ff);
+    mk_attn(mix, I, false);
+    mk_attn(dec, d, true);
+    layers.resize(c.depth);
+    for (auto& l : layers) {
+        l.w_qk = B16((size_t)2 * I * d); l.w_v = B16((size_t)I * d); l.w_o = B16((size_t)d * I); l.b_o = F32(d);
+        l.ng = F32(d); l.nb = F32(d);
+        mk_ff(l.ff);
+    }
+    s_lat = F32((size_t)M * d);
+    d_lat = F32((size_t)M * d);
+    q1 = B16((size_t)M * I);
+    w_qp = B16((size_t)d * d); b_qp = F32(d);
+    w_proj = F32((size_t)d * L); b_proj = F32(d);
+    w_ml = B16((size_t)2 * L * d); b_ml = F32((size_t)2 * L);
+    wq_dec_t = B16((size_t)d * d);
+    w_fold = F32(d);
+    std::vector<int> rm = geglu_rowmap(4 * d);
+    d_geglu_map = (int*)arena.alloc(rm.size() * 4, false);
+    RALD_CHECK(d_geglu_map && w_fold && wq_dec_t, "ae: device allocation failed");
+    RALD_HIP(hipMemcpy(d_geglu_map, rm.data(), rm.size() * 4, hipMemcpyHostToDevice));
+
+    expected.clear();
+    char buf[160];
+    auto add_attn = [&](const std::string& p, bool ctx) {
+        for (const char* n : {"fn.to_q.weight", "fn.to_kv.weight", "fn.to_out.weight", "fn.to_out.bias", "norm.weight", "norm.bias"})
+            expected.insert(p + n);
+        if (ctx) { expected.insert(p + "norm_context.weight"); expected.insert(p + "norm_context.bias"); }
+    };
+    auto add_ff = [&](const std::string& p) {
+        for (const char* n : {"fn.net.0.weight", "fn.net.0.bias", "fn.net.2.weight", "fn.net.2.bias", "norm.weight", "norm.bias"})
+            expected.insert(p + n);
+    };
+    add_attn("cross_attend_blocks.0.", true);
+    add_ff("cross_attend_blocks.1.");
+    for (const char* n : {"point_embed.basis", "point_embed.mlp.weight", "point_embed.mlp.bias", "s_latents.weight", "d_latents.weight",
+                          "query_proj.weight", "query_proj.bias", "to_outputs.weight", "to_outputs.bias", "proj.weight", "proj.bias",
+                          "mean_fc.weight", "mean_fc.bias", "logvar_fc.weight", "logvar_fc.bias"})
+        expected.insert(n);
+    add_attn("mix_attn_layer.", false);
+    add_attn("decoder_cross_attn.", true);
+    for (int i = 0; i < c.depth; ++i) {
+        snprintf(buf, sizeof(buf), "layers.%d.0.", i); add_attn(buf, false);
+        snprintf(buf, sizeof(buf), "layers.%d.1.", i); add_ff(buf);
+    }
+    return 0;
+}
+
+int Ae::load_attn(AttnW& a, int inner, const std::string& t, const float* data, int64_t nelem, bool* handled) {
+    *handled = true;
+    auto need = [&](int64_t n) -> int { RALD_CHECK(nelem == n, "ae: size mismatch for an attention tensor (" + t + ")"); return 0; };
+    if (t == "fn.to_q.weight") { RALD_TRY(need((int64_t)inner * d)); return stager.to_bf16(data, a.w_q, inner, d, d, nullptr); }
+    if (t == "fn.to_kv.weight") {     // first half of the rows is k, second half v (models_ae.py:89)
+        RALD_TRY(need((int64_t)2 * inner * d));
+        RALD_TRY(stager.fetch(data, nelem));
+        RALD_TRY(pack_rows_bf16((const float*)stager.buf, a.w_k, inner, d, d, nullptr, nullptr));
+        RALD_TRY(pack_rows_bf16((const float*)stager.buf + (size_t)inner * d, a.w_v, inner, d, d, nullptr, nullptr));
+        RALD_HIP(hipDeviceSynchronize());
+        return 0;
+    }
+    if (t == "fn.to_out.weight") { RALD_TRY(need((int64_t)d * inner)); return stager.to_bf16(data, a.w_o, d, inner, inner, nullptr); }
+    if (t == "fn.to_out.bias") { RALD_TRY(need(d)); return stager.to_f32(data, a.b_o, 1, d, d, nullptr); }
+    if (t == "norm.weight") { RALD_TRY(need(d)); return stager.to_f32(data, a.ng, 1, d, d, nullptr); }
+    if (t == "norm.bias") { RALD_TRY(need(d)); return stager.to_f32(data, a.nb, 1, d, d, nullptr); }
+    if (t == "norm_context.weight" && a.cg) { RALD_TRY(need(d)); return stager.to_f32(data, a.cg, 1, d, d, nullptr); }
+    if (t == "norm_context.bias" && a.cb) { RALD_TRY(need(d)); return stager.to_f32(data, a.cb, 1, d, d, nullptr); }
+    *handled = false;
+    return 0;
+}
+
+int Ae::load_ff(FfW& f, const std::string& t, const float* data, int64_t nelem, bool* handled) {
+    *handled = true;
+    auto need = [&](int64_t n) -> int { RALD_CHECK(nelem == n, "ae: size mismatch for a feed-forward tensor (" + t + ")"); return 0; };
+    if (t == "fn.net.0.weight") { RALD_TRY(need((int64_t)8 * d * d)); return stager.to_bf16(data, f.w1, 8 * d, d, d, d_geglu_map); }
+    if (t == "fn.net.0.bias") { RALD_TRY(need((int64_t)8 * d)); return stager.to_f32(data, f.b1, 8 * d, 1, 1, d_geglu_map); }
+    if (t == "fn.net.2.weight") { RALD_TRY(need((int64_t)d * 4 * d)); return stager.to_bf16(data, f.w2, d, 4 * d, 4 * d, nullptr); }
+    if (t == "fn.net.2.bias") { RALD_TRY(need(d)); return stager.to_f32(data, f.b2, 1, d, d, nullptr); }
+    if (t == "norm.weight") { RALD_TRY(need(d)); return stager.to_f32(data, f.ng, 1, d, d, nullptr); }
+    if (t == "norm.bias") { RALD_TRY(need(d)); return stager.to_f32(data, f.nb, 1, d, d, nullptr); }
+    *handled = false;
+    return 0;
+}
+
+int Ae::load_weight(const std::string& name, const float* data, int64_t nelem) {
+    RALD_CHECK(expected.count(name), "ae: unexpected key '" + name + "'");
+    const int M = cfg.num_latents, L = cfg.latent_dim;
+    auto need = [&](int64_t n) -> int {
+        RALD_CHECK(nelem == n, "ae: size mismatch for '" + name + "': got " + std::to_string(nelem) + ", expected " + std::to_string(n));
+        return 0;
+    };
+    bool handled = false;
+    int rc = 0, li = -1, sub = -1;
+    char tail[128] = {0};
+    if (name.rfind("cross_attend_blocks.0.", 0) == 0) rc = load_attn(cross, d, name.substr(22), data, nelem, &handled);
+    else if (name.rfind("cross_attend_blocks.1.", 0) == 0) rc = load_ff(cross_ff, name.substr(22), data, nelem, &handled);
+    else if (name.rfind("mix_attn_layer.", 0) == 0) rc = load_attn(mix, I, name.substr(15), data, nelem, &handled);
+    else if (name.rfind("decoder_cross_attn.", 0) == 0) {
+        const std::string t = name.substr(19);
+        // host copies of the tensors that are folded at finalize()
+        if (t == "fn.to_q.weight") RALD_TRY(fetch_host(h_dec_wq, data, nelem));
+        if (t == "fn.to_kv.weight") RALD_TRY(fetch_host(h_dec_wkv, data, nelem));
+        if (t == "fn.to_out.weight") RALD_TRY(fetch_host(h_dec_wo, data, nelem));
+        if (t == "fn.to_out.bias") RALD_TRY(fetch_host(h_dec_bo, data, nelem));
+        rc = load_attn(dec, d, t, data, nelem, &handled);
+    } else if (sscanf(name.c_str(), "layers.%d.%d.%127s", &li, &sub, tail) == 3) {
+        RALD_CHECK(li >= 0 && li < cfg.depth && (sub == 0 || sub == 1), "ae: bad layer index in '" + name + "'");
+        Layer& l = layers[li];
+        const std::string t(tail);
+        if (sub == 1) rc = load_ff(l.ff, t, data, nelem, &handled);
+        else {
+            handled = true;
+            if (t == "fn.to_q.weight") { RALD_TRY(need((int64_t)I * d)); rc = stager.to_bf16(data, l.w_qk, I, d, d, nullptr); }
+            else if (t == "fn.to_kv.weight") {
+                RALD_TRY(need((int64_t)2 * I * d));
+                RALD_TRY(stager.fetch(data, nelem));
+                RALD_TRY(pack_rows_bf16((const float*)stager.buf, l.w_qk + (size_t)I * d, I, d, d, nullptr, nullptr));
+                RALD_TRY(pack_rows_bf16((const float*)stager.buf + (size_t)I * d, l.w_v, I, d, d, nullptr, nullptr));
+                RALD_HIP(hipDeviceSynchronize());
+            }
+            else if (t == "fn.to_out.weight") { RALD_TRY(need((int64_t)d * I)); rc = stager.to_bf16(data, l.w_o, d, I, I, nullptr); }
+            else if (t == "fn.to_out.bias") { RALD_TRY(need(d)); rc = stager.to_f32(data, l.b_o, 1, d, d, nullptr); }
+            else if (t == "norm.weight") { RALD_TRY(need(d)); rc = stager.to_f32(data, l.ng, 1, d, d, nullptr); }
+            else if (t == "norm.bias") { RALD_TRY(need(d)); rc = stager.to_f32(data, l.nb, 1, d, d, nullptr); }
+            else handled = false;
+        }
+    } else {
+        handled = true;
+        if (name == "point_embed.basis") { RALD_TRY(need(72)); rc = stager.to_f32(data, basis, 1, 72, 72, nullptr); }
+        else if (name == "point_embed.mlp.weight") { RALD_TRY(need((int64_t)d * 51)); rc = stager.to_bf16(data, w_pe, d, 51, 64, nullptr); }
+        else if (name == "point_embed.mlp.bias") { RALD_TRY(need(d)); rc = stager.to_f32(data, b_pe, 1, d, d, nullptr); }
+        else if (name == "s_latents.weight") { RALD_TRY(need((int64_t)M * d)); rc = stager.to_f32(data, s_lat, M, d, d, nullptr); }
+        else if (name == "d_latents.weight") { RALD_TRY(need((int64_t)M * d)); rc = stager.to_f32(data, d_lat, M, d, d, nullptr); }
+        else if (name == "query_proj.weight") { RALD_TRY(need((int64_t)d * d)); rc = stager.to_bf16(data, w_qp, d, d, d, nullptr); }
+        else if (name == "query_proj.bias") { RALD_TRY(need(d)); rc = stager.to_f32(data, b_qp, 1, d, d, nullptr); }
+        else if (name == "to_outputs.weight") { RALD_TRY(need(d)); rc = fetch_host(h_out_w, data, nelem); }
+        else if (name == "to_outputs.bias") { RALD_TRY(need(1)); rc = fetch_host(h_out_b, data, nelem); }
+        else if (name == "proj.weight") { RALD_TRY(need((int64_t)d * L)); rc = stager.to_f32(data, w_proj, d, L, L, nullptr); }
+        else if (name == "proj.bias") { RALD_TRY(need(d)); rc = stager.to_f32(data, b_proj, 1, d, d, nullptr); }
+        else if (name == "mean_fc.weight") { RALD_TRY(need((int64_t)L * d)); rc = stager.to_bf16(data, w_ml, L, d, d, nullptr); }
+        else if (name == "logvar_fc.weight") { RALD_TRY(need((int64_t)L * d)); rc = stager.to_bf16(data, w_ml + (size_t)L * d, L, d, d, nullptr); }
+        else if (name == "mean_fc.bias") { RALD_TRY(need(L)); rc = stager.to_f32(data, b_ml, 1, L, L, nullptr); }
+        else if (name == "logvar_fc.bias") { RALD_TRY(need(L)); rc = stager.to_f32(data, b_ml + L, 1, L, L, nullptr); }
+        else handled = false;
+    }
+    if (rc) return rc;
+    RALD_CHECK(handled, "ae: unknown key '" + name + "'");
+    loaded.insert(name);
+    finalized = false;
+    return 0;
+}
+
+int Ae::finalize() {
+    for (const auto& k : expected) RALD_CHECK(loaded.count(k), "ae: missing key '" + k + "' (strict load)");
+    const int M = cfg.num_latents;
+    // (1) the mix layer's query is input-independent: q1 = to_q(LN(d_latents))      (:383-384)
+    bf16* tmp = (bf16*)arena.alloc((size_t)M * d * 2, true);
+    RALD_CHECK(tmp, "ae: allocation failed");
+    RALD_TRY(layernorm_mod(d_lat, tmp, M, d, mix.ng, mix.nb, 0, 1 << 30, 0.f, 1e-5f, nullptr));
+    GemmArgs g = gemm_args(tmp, d, mix.w_q, d, q1, I, nullptr, M, I, d);
+    RALD_TRY(gemm_nt(g, EPI_BF16, nullptr));
+    RALD_HIP(hipDeviceSynchronize());
+    arena.release(tmp);
+    // (2) decoder folding, in double on the host:
+    //     wo' = Wo^T.w_out [d];  w_fold = Wv^T.wo' [d];  c0 = b_o.w_out + b_out;  WqT for G = K.Wq
+    RALD_CHECK((int64_t)h_dec_wq.size() == (int64_t)d * d && (int64_t)h_dec_wkv.size() == (int64_t)2 * d * d &&
+               (int64_t)h_dec_wo.size() == (int64_t)d * d && (int)h_dec_bo.size() == d && (int)h_out_w.size() == d && h_out_b.size() == 1,
+               "ae: decoder tensors missing for folding");
+    std::vector<double> wo1(d, 0.0);
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) wo1[j] += (double)h_dec_wo[(size_t)i * d + j] * h_out_w[i];
+    std::vector<float> wf(d);
+    const float* Wv = h_dec_wkv.data() + (size_t)d * d;
+    for (int c = 0; c < d; ++c) {
+        double s = 0.0;
+        for (int j = 0; j < d; ++j) s += (double)Wv[(size_t)j * d + c] * wo1[j];
+        wf[c] = (float)s;
+    }
+    double c = h_out_b[0];
+    for (int i = 0; i < d; ++i) c += (double)h_dec_bo[i] * h_out_w[i];
+    c0 = (float)c;
+    RALD_HIP(hipMemcpy(w_fold, wf.data(), (size_t)d * 4, hipMemcpyHostToDevice));
+    std::vector<float> wqt((size_t)d * d);
+    for (int j = 0; j < d; ++j)
+        for (int cc = 0; cc < d; ++cc) wqt[(size_t)cc * d + j] = h_dec_wq[(size_t)j * d + cc];
+    RALD_TRY(stager.to_bf16(wqt.data(), wq_dec_t, d, d, d, nullptr));
+    finalized = true;
+    return 0;
+}
+
+int Ae::reserve_encode(int B) {
+    if (B <= enc_batch) return 0;
+    RALD_HIP(hipDeviceSynchronize());
+    for (void** p : enc_ptrs()) if (*p) { arena.release(*p); *p = nullptr; }
+    const size_t P = cfg.num_inputs, Pp = round_up(P, 64), M = cfg.num_latents, L = cfg.latent_dim;
+    const size_t b = B;
+    e_feat = (bf16*)arena.alloc(b * P * 64 * 2, true);
+    e_emb32 = (float*)arena.alloc(b * P * d * 4, true);
+    e_emb16 = (bf16*)arena.alloc(b * P * d * 2, true);
+    e_embn16 = (bf16*)arena.alloc(b * P * d * 2, true);
+    e_k = (bf16*)arena.alloc(b * Pp * 512 * 2, true);           // K1 [B][Pp][I] then reused as K2 [B][Pp][d] (d <= I)
+    e_vt = (bf16*)arena.alloc(b * 512 * Pp * 2, true);          // Vt1 [B][I][Pp] then Vt2 [B][d][Pp]
+    e_o = (bf16*)arena.alloc(b * M * 512 * 2, true);
+    e_dq = (float*)arena.alloc(b * M * d * 4, true);
+    e_xq = (bf16*)arena.alloc(b * M * d * 2, true);
+    e_x = (float*)arena.alloc(b * M * d * 4, true);
+    e_h = (bf16*)arena.alloc(b * M * d * 2, true);
+    e_q2 = (bf16*)arena.alloc(b * M * d * 2, true);
+    e_s = (float*)arena.alloc(b * M * Pp * 4, true);
+    e_p = (bf16*)arena.alloc(b * M * Pp * 2, true);
+    e_g = (bf16*)arena.alloc(b * M * 4 * d * 2, true);
+    e_ml = (float*)arena.alloc(b * M * 2 * L * 4, true);
+    for (void** p : enc_ptrs()) RALD_CHECK(*p, "ae: encode workspace allocation failed");
+    enc_batch = B;
+    return 0;
+}
+
+int Ae::encode(const float* pc, int B, const float* eps, float* mean_o, float* logvar_o, float* z, float* kl, hipStream_t st) {
+    RALD_CHECK(finalized, "ae: weights not finalized");
+    RALD_CHECK(pc && eps && z && kl && B >= 1, "ae: bad arguments");
+    RALD_TRY(reserve_encode(B));
+    const int P = cfg.num_inputs, Pp = (int)round_up(P, 64), M = cfg.num_latents, L = cfg.latent_dim;
+    const int BM = B * M;
+    // ---- PointEmbed (:355)
+    RALD_TRY(point_features(pc, basis, e_feat, (int64_t)B * P, st));
+    GemmArgs pe = gemm_args(e_feat, 64, w_pe, 64, e_emb32, d, b_pe, B * P, d, 64);
+    RALD_TRY(gemm_nt(pe, EPI_F32, st));
+    RALD_TRY(cast_f32_bf16(e_emb32, e_emb16, (int64_t)B * P * d, st));
+    // ---- mix query: dynamic_query = mix_attn_layer(d_latents, context=pc_embeddings) (:384; context NOT normed)
+    GemmArgs k1 = gemm_args(e_emb16, d, mix.w_k, d, e_k, I, nullptr, P, I, d);
+    k1.batch = B; k1.strideA = (int64_t)P * d; k1.strideC = (int64_t)Pp * I;
+    RALD_TRY(gemm_nt(k1, EPI_BF16, st));
+    GemmArgs v1 = gemm_args(mix.w_v, d, e_emb16, d, e_vt, Pp, nullptr, I, P, d);
+    v1.batch = B; v1.strideB = (int64_t)P * d; v1.strideC = (int64_t)I * Pp;
+    RALD_TRY(gemm_nt(v1, EPI_BF16, st));
+    AttnArgs a1;
+    a1.Q = q1; a1.ldq = I; a1.strideQ = 0;
+    a1.K = e_k; a1.ldk = I; a1.strideK = (int64_t)Pp * I;
+    a1.Vt = e_vt; a1.ldvt = Pp; a1.strideVt = (int64_t)I * Pp;
+    a1.O = e_o; a1.ldo = I; a1.strideO = (int64_t)M * I;
+    a1.nq = M; a1.nk = P; a1.k_rows = Pp; a1.heads = cfg.heads; a1.batch = B; a1.scale = 1.0f / sqrtf((float)cfg.dim_head);
+    RALD_TRY(attention_d64(a1, st));
+    GemmArgs o1 = gemm_args(e_o, I, mix.w_o, I, e_dq, d, mix.b_o, BM, d, I);
+    RALD_TRY(gemm_nt(o1, EPI_F32, st));
+    // ---- x = query_proj(static_query + dynamic_query)                            (:385-386)
+    RALD_TRY(add_bcast_cast(s_lat, e_dq, e_xq, (int64_t)M * d, B, st));
+    GemmArgs qp = gemm_args(e_xq, d, w_qp, d, e_x, d, b_qp, BM, d, d);
+    RALD_TRY(gemm_nt(qp, EPI_F32, st));
+    // ---- x = cross_attn(x, context=pc_embeddings) + x   (1 head x dim, both normed) (:395)
+    RALD_TRY(layernorm_mod(e_emb32, e_embn16, B * P, d, cross.cg, cross.cb, 0, 1 << 30, 0.f, 1e-5f, st));
+    RALD_TRY(layernorm_mod(e_x, e_h, BM, d, cross.ng, cross.nb, 0, 1 << 30, 0.f, 1e-5f, st));
+    GemmArgs q2 = gemm_args(e_h, d, cross.w_q, d, e_q2, d, nullptr, BM, d, d);
+    RALD_TRY(gemm_nt(q2, EPI_BF16, st));
+    GemmArgs k2 = gemm_args(e_embn16, d, cross.w_k, d, e_k, d, nullptr, P, d, d);
+    k2.batch = B; k2.strideA = (int64_t)P * d; k2.strideC = (int64_t)Pp * d;
+    RALD_TRY(gemm_nt(k2, EPI_BF16, st));
+    GemmArgs v2 = gemm_args(cross.w_v, d, e_embn16, d, e_vt, Pp, nullptr, d, P, d);
+    v2.batch = B; v2.strideB = (int64_t)P * d; v2.strideC = (int64_t)d * Pp;
+    RALD_TRY(gemm_nt(v2, EPI_BF16, st));
+    // S = q.k^T * dim^-1/2, materialised in fp32 ([M x P] per sample is only 20 MB): softmax -> P bf16 -> P.V
+    GemmArgs s = gemm_args(e_q2, d, e_k, d, e_s, Pp, nullptr, M, P, d);
+    s.batch = B; s.strideA = (int64_t)M * d; s.strideB = (int64_t)Pp * d; s.strideC = (int64_t)M * Pp;
+    s.alpha = 1.0f / sqrtf((float)d);
+    RALD_TRY(gemm_nt(s, EPI_F32, st));
+    RALD_TRY(softmax_rows(e_s, Pp, e_p, Pp, BM, P, st));
+    GemmArgs pv = gemm_args(e_p, Pp, e_vt, Pp, e_o, d, nullptr, M, d, Pp);
+    pv.batch = B; pv.strideA = (int64_t)M * Pp; pv.strideB = (int64_t)d * Pp; pv.strideC = (int64_t)M * d;
+    RALD_TRY(gemm_nt(pv, EPI_BF16, st));
+    GemmArgs o2 = gemm_args(e_o, d, cross.w_o, d, e_x, d, cross.b_o, BM, d, d);
+    RALD_TRY(gemm_nt(o2, EPI_RESID, st));
+    // ---- x = cross_ff(x) + x                                                      (:396)
+    RALD_TRY(layernorm_mod(e_x, e_h, BM, d, cross_ff.ng, cross_ff.nb, 0, 1 << 30, 0.f, 1e-5f, st));
+    GemmArgs f1 = gemm_args(e_h, d, cross_ff.w1, d, e_g, 4 * d, cross_ff.b1, BM, 8 * d, d);
+    RALD_TRY(gemm_nt(f1, EPI_GEGLU, st));
+    GemmArgs f2 = gemm_args(e_g, 4 * d, cross_ff.w2, 4 * d, e_x, d, cross_ff.b2, BM, d, 4 * d);
+    RALD_TRY(gemm_nt(f2, EPI_RESID, st));
+    // ---- mean / logvar (:398-399) and the posterior (:401-403)
+    RALD_TRY(cast_f32_bf16(e_x, e_h, (int64_t)BM * d, st));
+    GemmArgs ml = gemm_args(e_h, d, w_ml, d, e_ml, 2 * L, b_ml, BM, 2 * L, d);
+    RALD_TRY(gemm_nt(ml, EPI_F32, st));
+    RALD_TRY(posterior(e_ml, eps, mean_o, logvar_o, z, kl, B, M, L, st));
+    return 0;
+}
+
+int Ae::reserve_decode(int B) {
+    if (B <= dec_batch) return 0;
+    RALD_HIP(hipDeviceSynchronize());
+    for (void** p : dec_ptrs()) if (*p) { arena.release(*p); *p = nullptr; }
+    const size_t M = cfg.num_latents, b = B;
+    x_x = (float*)arena.alloc(b * M * d * 4, true);
+    x_h = (bf16*)arena.alloc(b * M * d * 2, true);
+    x_qk = (bf16*)arena.alloc(b * M * 2 * I * 2, true);
+    x_vt = (bf16*)arena.alloc(b * I * M * 2, true);
+    x_o = (bf16*)arena.alloc(b * M * I * 2, true);
+    x_g = (bf16*)arena.alloc(b * M * 4 * d * 2, true);
+    x_kd = (bf16*)arena.alloc(b * M * d * 2, true);
+    for (void** p : dec_ptrs()) RALD_CHECK(*p, "ae: decode workspace allocation failed");
+    dec_batch = B;
+    return 0;
+}
+
+int64_t Ae::ctx_bytes(int B) const {
+    // G [B][M][d] bf16 + u [B][M] f32
+    return (int64_t)B * cfg.num_latents * d * 2 + (int64_t)B * cfg.num_latents * 4;
+}
+
+int Ae::decode_latents(const float* z, int B, void* ctx, hipStream_t st) {
+    RALD_CHECK(finalized, "ae: weights not finalized");
+    RALD_CHECK(z && ctx && B >= 1 && (uintptr_t)ctx % 16 == 0, "ae: bad arguments");
+    RALD_TRY(reserve_decode(B));
+    const int M = cfg.num_latents, L = cfg.latent_dim, BM = B * M;
+    const float scale = 1.0f / sqrtf((float)cfg.dim_head);
+    RALD_TRY(small_k_linear(z, w_proj, b_proj, x_x, BM, L, d, st));                     // x = proj(z)  (:410)
+    for (const Layer& l : layers) {
+        // x = self_attn(x) + x                                                         (:413)
+        RALD_TRY(layernorm_mod(x_x, x_h, BM, d, l.ng, l.nb, 0, 1 << 30, 0.f, 1e-5f, st));
+        GemmArgs qk = gemm_args(x_h, d, l.w_qk, d, x_qk, 2 * I, nullptr, BM, 2 * I, d);
+        RALD_TRY(gemm_nt(qk, EPI_BF16, st));
+        GemmArgs vt = gemm_args(l.w_v, d, x_h, d, x_vt, M, nullptr, I, M, d);
+        vt.batch = B; vt.strideB = (int64_t)M * d; vt.strideC = (int64_t)I * M;
+        RALD_TRY(gemm_nt(vt, EPI_BF16, st));
+        AttnArgs a;
+        a.Q = x_qk; a.ldq = 2 * I; a.strideQ = (int64_t)M * 2 * I;
+        a.K = x_qk + I; a.ldk = 2 * I; a.strideK = (int64_t)M * 2 * I;
+        a.Vt = x_vt; a.ldvt = M; a.strideVt = (int64_t)I * M;
+        a.O = x_o; a.ldo = I; a.strideO = (int64_t)M * I;
+        a.nq = M; a.nk = M; a.k_rows = M; a.heads = cfg.heads; a.batch = B; a.scale = scale;
+        RALD_TRY(attention_d64(a, st));
+        GemmArgs o = gemm_args(x_o, I, l.w_o, I, x_x, d, l.b_o, BM, d, I);
+        RALD_TRY(gemm_nt(o, EPI_RESID, st));
+        // x = self_ff(x) + x                                                            (:414)
+        RALD_TRY(layernorm_mod(x_x, x_h, BM, d, l.ff.ng, l.ff.nb, 0, 1 << 30, 0.f, 1e-5f, st));
+        GemmArgs f1 = gemm_args(x_h, d, l.ff.w1, d, x_g, 4 * d, l.ff.b1, BM, 8 * d, d);
+        RALD_TRY(gemm_nt(f1, EPI_GEGLU, st));
+        GemmArgs f2 = gemm_args(x_g, 4 * d, l.ff.w2, 4 * d, x_x, d, l.ff.b2, BM, d, 4 * d);
+        RALD_TRY(gemm_nt(f2, EPI_RESID, st));
+    }
+    // decoder context: K = to_k(LN_ctx(x)); G = K.Wq (per sample); u = LN_ctx(x).w_fold
+    bf16* G = (bf16*)ctx;
+    float* u = (float*)((char*)ctx + (size_t)B * M * d * 2);
+    RALD_TRY(layernorm_mod(x_x, x_h, BM, d, dec.cg, dec.cb, 0, 1 << 30, 0.f, 1e-5f, st));
+    GemmArgs kd = gemm_args(x_h, d, dec.w_k, d, x_kd, d, nullptr, BM, d, d);
+    RALD_TRY(gemm_nt(kd, EPI_BF16, st));
+    GemmArgs gg = gemm_args(x_kd, d, wq_dec_t, d, G, d, nullptr, BM, d, d);
+    RALD_TRY(gemm_nt(gg, EPI_BF16, st));
+    RALD_TRY(ln_dot(x_x, dec.cg, dec.cb, w_fold, u, BM, d, st));
+    return 0;
+}
+
+int Ae::reserve_queries(int64_t rows) {
+    if (rows <= q_rows) return 0;
+    RALD_HIP(hipDeviceSynchronize());
+    for (void** p : qry_ptrs()) if (*p) { arena.release(*p); *p = nullptr; }
+    const size_t M = cfg.num_latents, r = (size_t)rows;
+    y_feat = (bf16*)arena.alloc(r * 64 * 2, true);
+    y_qe = (float*)arena.alloc(r * d * 4, true);
+    y_qn = (bf16*)arena.alloc(r * d * 2, true);
+    y_s = (float*)arena.alloc(r * M * 4, true);
+    for (void** p : qry_ptrs()) RALD_CHECK(*p, "ae: query workspace allocation failed");
+    q_rows = rows;
+    return 0;
+}
+
+int Ae::decode_queries(const void* ctx, const float* q, int B, int64_t Q, float* out, hipStream_t st) {
+    RALD_CHECK(finalized, "ae: weights not finalized");
+    RALD_CHECK(ctx && q && out && B >= 1 && Q >= 1, "ae: bad arguments");
+    const int M = cfg.num_latents;
+    const int64_t chunk = Q < QUERY_CHUNK ? Q : QUERY_CHUNK;
+    RALD_TRY(reserve_queries(chunk));
+    const bf16* G = (const bf16*)ctx;
+    const float* u = (const float*)((const char*)ctx + (size_t)B * M * d * 2);
+    const float scale = 1.0f / sqrtf((float)d);
+    for (int b = 0; b < B; ++b) {
+        for (int64_t off = 0; off < Q; off += chunk) {
+            const int n = (int)((Q - off) < chunk ? (Q - off) : chunk);
+            const float* qp = q + ((int64_t)b * Q + off) * 3;
+            RALD_TRY(point_features(qp, basis, y_feat, n, st));
+            GemmArgs pe = gemm_args(y_feat, 64, w_pe, 64, y_qe, d, b_pe, n, d, 64);
+            RALD_TRY(gemm_nt(pe, EPI_F32, st));
+            RALD_TRY(layernorm_mod(y_qe, y_qn, n, d, dec.ng, dec.nb, 0, 1 << 30, 0.f, 1e-5f, st));
+            GemmArgs s = gemm_args(y_qn, d, G + (size_t)b * M * d, d, y_s, M, nullptr, n, M, d);
+            s.alpha = scale;
+            RALD_TRY(gemm_nt(s, EPI_F32, st));
+            float* o = out + (int64_t)b * Q + off;
+            if (M == 256 || M == 512 || M == 1024) RALD_TRY(softmax_dot(y_s, u + (size_t)b * M, o, n, M, 1 << 30, c0, st));
+            else RALD_TRY(softmax_dot_generic(y_s, u + (size_t)b * M, o, n, M, 1 << 30, c0, st));
+        }
+    }
+    return 0;
+}
+
+}  // namespace rald

@@ -1,9 +1,11 @@
 // extern "C" surface of librald_hip.so (include/rald_hip.h).  Thin: argument checks + dispatch.
+#include "ae.h"
 #include "dit.h"
 
 using namespace rald;
 
 struct rald_dit { Dit impl; };
+struct rald_ae { Ae impl; };
 
 extern "C" {
 
@@ -69,6 +71,42 @@ int rald_dit_profile_end(rald_dit* h, double* total_ms, int32_t* launches) {
     int rc = h->impl.profile_end(total_ms, &n);
     *launches = n;
     return rc;
+}
+
+// ---- autoencoder ---------------------------------------------------------------------------------
+int rald_ae_create(const rald_ae_config* cfg, rald_ae** out) {
+    RALD_CHECK(cfg && out, "rald_ae_create: null argument");
+    rald_ae* h = new rald_ae();
+    h->impl.cfg = *cfg;
+    int rc = h->impl.create();
+    if (rc) { delete h; return rc; }
+    *out = h;
+    return 0;
+}
+void rald_ae_destroy(rald_ae* h) {
+    if (!h) return;
+    (void)hipDeviceSynchronize();
+    delete h;
+}
+int rald_ae_load_weight(rald_ae* h, const char* name, const float* data, int64_t nelem) {
+    RALD_CHECK(h && name && data, "rald_ae_load_weight: null argument");
+    return h->impl.load_weight(name, data, nelem);
+}
+int rald_ae_finalize(rald_ae* h) { RALD_CHECK(h, "null handle"); return h->impl.finalize(); }
+int rald_ae_encode(rald_ae* h, const float* pc, int32_t batch, const float* eps, float* out_mean, float* out_logvar,
+                   float* out_z, float* out_kl, void* stream) {
+    RALD_CHECK(h, "null handle");
+    return h->impl.encode(pc, batch, eps, out_mean, out_logvar, out_z, out_kl, (hipStream_t)stream);
+}
+int64_t rald_ae_ctx_bytes(const rald_ae* h, int32_t batch) { return h ? h->impl.ctx_bytes(batch) : -1; }
+int rald_ae_decode_latents(rald_ae* h, const float* z, int32_t batch, void* ctx, void* stream) {
+    RALD_CHECK(h, "null handle");
+    return h->impl.decode_latents(z, batch, ctx, (hipStream_t)stream);
+}
+int rald_ae_decode_queries(rald_ae* h, const void* ctx, const float* queries, int32_t batch, int64_t n_queries,
+                           float* out_logits, void* stream) {
+    RALD_CHECK(h, "null handle");
+    return h->impl.decode_queries(ctx, queries, batch, n_queries, out_logits, (hipStream_t)stream);
 }
 
 // ---- kernel-level entry points -----------------------------------------------------------------

@@ -64,4 +64,14 @@ int heun_euler(const float* x_hat, const float* denoised, float t_hat, float t_n
 int heun_correct(const float* x_hat, const float* x_euler, const float* denoised, const float* d_cur,
                  float t_hat, float t_next, float* x_next, int64_t n, hipStream_t st);
 
+// ---------------------------------------------------------------- ae_kernels.hip
+int point_features(const float* pts, const float* basis, bf16* feat, int64_t n, hipStream_t st);
+int softmax_rows(const float* S, int64_t ld_s, bf16* P, int64_t ld_p, int rows, int n, hipStream_t st);
+int softmax_dot(const float* S, const float* u, float* out, int64_t rows, int nkeys, int rows_per_batch, float c0, hipStream_t st);
+int softmax_dot_generic(const float* S, const float* u, float* out, int64_t rows, int nkeys, int rows_per_batch, float c0, hipStream_t st);
+int ln_dot(const float* x, const float* gamma, const float* beta, const float* w, float* out, int M, int D, hipStream_t st);
+int add_bcast_cast(const float* a, const float* d, bf16* out, int64_t per_batch, int batch, hipStream_t st);
+int posterior(const float* ml, const float* eps, float* mean_o, float* logvar_o, float* z, float* kl, int B, int rows, int L, hipStream_t st);
+int small_k_linear(const float* in, const float* W, const float* bias, float* out, int M, int K, int N, hipStream_t st);
+
 }  // namespace rald
