@@ -1,18 +1,588 @@
-// Radar-spectrum encoder (model/models_radar_encoder.py Encoder) - placeholder until the
-// implicit-GEMM Conv3d kernels land: every entry point fails loudly, nothing falls back.
+// Radar-spectrum encoder (model/models_radar_encoder.py Encoder :137-241) and the tokeniser half of
+// EDMPrecond.process_radar_cond (models_radar_generation.py:363-407).
+//
+// Data layout (MI355X-first): activations are channels-LAST (NDHWC = [b][r][a][e][c]) so that one
+// voxel's channels are contiguous - exactly an MFMA A-fragment row - and the encoder's output
+// [B,8,4,2,16] is already in the `permute(0,2,3,4,1)` order the tokeniser wants (:387).  The
+// residual trunk stays fp32; every conv input is the bf16 tensor swish(GroupNorm(x)) written by
+// one HBM-bound pass (gn_apply), so the conv kernel is a pure implicit GEMM:
+//     M = output voxels, N = Cout, K = 27*Cin  (weights packed [Cout][tap][Cin], K-contiguous).
+// Conv3d zero padding applies to the normalised+activated tensor, i.e. out-of-range taps
+// contribute exact zeros (register zero-fill, no padded copy).  Downsample = F.pad(0,1) + conv
+// k3 s2 p0 (:37-41) is the same kernel with stride 2 and left pad 0.
 #include "dit.h"
 
+#include <cmath>
+#include <cstdio>
+#include <map>
+
 namespace rald {
-struct RadarEncoder::Impl {};
-int RadarEncoder::create(int, int, int, int, int, int, DeviceArena*) { return 0; }
-void RadarEncoder::expected_keys(const std::string&, std::set<std::string>&) const {}
-int RadarEncoder::load_weight(const std::string& name, const float*, int64_t, Stager&) {
-    RALD_CHECK(false, "radar encoder not built yet: cannot load '" + name + "'");
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+// conv_in: Cin = 1 -> ch (64); the cube's channel 0 is read in place ([B,R,A,E,cube_ch], :378).
+__global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ cube, int cube_ch, const float* __restrict__ W,
+                                                      const float* __restrict__ bias, float* __restrict__ out, int B, int D,
+                                                      int H, int Wd, int Cout) {
+    extern __shared__ float sw[];            // [27][Cout] (tap-major so 8 consecutive co are contiguous)
+    for (int i = threadIdx.x; i < 27 * Cout; i += 256) {
+        const int t = i / Cout, co = i % Cout;
+        sw[i] = W[co * 27 + t];
+    }
+    __syncthreads();
+    const int groups = Cout / 8;                          // threads per voxel
+    const int vpb = 256 / groups;                         // voxels per block
+    const int64_t v = (int64_t)blockIdx.x * vpb + threadIdx.x / groups;
+    const int cg = threadIdx.x % groups;
+    const int64_t nvox = (int64_t)B * D * H * Wd;
+    if (v >= nvox) return;
+    int w = (int)(v % Wd);
+    int64_t r = v / Wd;
+    int h = (int)(r % H); r /= H;
+    int d = (int)(r % D);
+    int b = (int)(r / D);
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = bias[cg * 8 + i];
+    for (int kd = 0; kd < 3; ++kd)
+        for (int kh = 0; kh < 3; ++kh)
+            for (int kw = 0; kw < 3; ++kw) {
+                const int id = d + kd - 1, ih = h + kh - 1, iw = w + kw - 1;
+                if ((unsigned)id >= (unsigned)D || (unsigned)ih >= (unsigned)H || (unsigned)iw >= (unsigned)Wd) continue;
+                const float x = cube[((((int64_t)b * D + id) * H + ih) * Wd + iw) * cube_ch];
+                const float* wt = sw + ((kd * 3 + kh) * 3 + kw) * Cout + cg * 8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] += x * wt[i];
+            }
+    float4* o = reinterpret_cast<float4*>(out + v * Cout + cg * 8);
+    o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
 }
-int RadarEncoder::load_token_weight(const std::string& name, const float*, int64_t, Stager&) {
-    RALD_CHECK(false, "radar encoder not built yet: cannot load '" + name + "'");
+
+// GroupNorm statistics (32 groups): stats[b][g] = {sum, sumsq} in double via atomics; x [B][S][C] fp32.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int S, int C,
+                                                       int vox_per_block) {
+    __shared__ float ssum[32], ssq[32];
+    if (threadIdx.x < 32) { ssum[threadIdx.x] = 0.f; ssq[threadIdx.x] = 0.f; }
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int quads = C / 4;                               // float4 pieces per voxel
+    const int q = threadIdx.x % quads;
+    const int vstep = 256 / quads;
+    const int v0 = blockIdx.x * vox_per_block;
+    const int v1 = min(S, v0 + vox_per_block);
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;         // channel pairs (4q,4q+1) and (4q+2,4q+3)
+    for (int v = v0 + threadIdx.x / quads; v < v1; v += vstep) {
+        const float4 t = reinterpret_cast<const float4*>(x + ((int64_t)b * S + v) * C)[q];
+        s0 += t.x + t.y; q0 += t.x * t.x + t.y * t.y;
+        s1 += t.z + t.w; q1 += t.z * t.z + t.w * t.w;
+    }
+    const int cpg = C / 32;
+    const int g0 = (4 * q) / cpg, g1 = (4 * q + 2) / cpg;
+    atomicAdd(&ssum[g0], s0); atomicAdd(&ssq[g0], q0);
+    atomicAdd(&ssum[g1], s1); atomicAdd(&ssq[g1], q1);
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        atomicAdd(&stats[((int64_t)b * 32 + threadIdx.x) * 2 + 0], (double)ssum[threadIdx.x]);
+        atomicAdd(&stats[((int64_t)b * 32 + threadIdx.x) * 2 + 1], (double)ssq[threadIdx.x]);
+    }
 }
-int RadarEncoder::tokens(const float*, int, float**, hipStream_t) { RALD_CHECK(false, "radar encoder not built yet"); }
-int RadarEncoder::encode(const float*, int, int, float**, hipStream_t) { RALD_CHECK(false, "radar encoder not built yet"); }
+
+// y_bf16 = act(GroupNorm(x)) with per-channel affine; act = swish (x*sigmoid(x), :5-7) or identity.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       bf16* __restrict__ y, int S, int C, float eps, int do_swish) {
+    __shared__ float smean[32], srstd[32];
+    const int b = blockIdx.y;
+    const int quads = C / 4;
+    const int cpg = C / 32;
+    if (threadIdx.x < 32) {
+        const double n = (double)S * cpg;
+        const double su = stats[((int64_t)b * 32 + threadIdx.x) * 2], sq = stats[((int64_t)b * 32 + threadIdx.x) * 2 + 1];
+        const double mean = su / n;
+        const double var = sq / n - mean * mean;               // biased variance, as torch GroupNorm
+        smean[threadIdx.x] = (float)mean;
+        srstd[threadIdx.x] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
+    }
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)S * quads; i += (int64_t)gridDim.x * 256) {
+        const int q = (int)(i % quads);
+        const int64_t idx = (int64_t)b * S * quads + i;
+        const float4 t = reinterpret_cast<const float4*>(x)[idx];
+        const float4 gm = reinterpret_cast<const float4*>(gamma)[q];
+        const float4 bt = reinterpret_cast<const float4*>(beta)[q];
+        const float v[4] = {t.x, t.y, t.z, t.w};
+        const float gg[4] = {gm.x, gm.y, gm.z, gm.w};
+        const float bb[4] = {bt.x, bt.y, bt.z, bt.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int g = (4 * q + j) / cpg;
+            float yv = (v[j] - smean[g]) * srstd[g] * gg[j] + bb[j];
+            if (do_swish) yv = yv / (1.0f + __expf(-yv));
+            o[j] = yv;
+        }
+        reinterpret_cast<bf16x4*>(y)[idx] = pack4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// Implicit-GEMM Conv3d k3: same tile machinery as gemm_nt_kernel (128 voxels x 64 couts x 64 K,
+// 4 waves 2x2, XOR-swizzled double-buffered LDS); the A rows are gathered per tap.
+struct ConvArgs {
+    const bf16* in;      // [B][ID][IH][IW][Cin]
+    const bf16* w;       // [Cout][27][Cin]
+    const float* bias;   // [Cout]
+    const float* resid;  // [M][Cout] or nullptr
+    float* out;          // [M][Cout]
+    int B, ID, IH, IW, Cin, OD, OH, OW, Cout, stride, pad;
+};
+
+__global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvArgs a) {
+    constexpr int BM = 128, BN = 64, BK = 64;
+    constexpr int MT = BM / 32, NT = BN / 32, PA = BM / 32, PB = BN / 32;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * BK * 2];
+    bf16x8* sA = reinterpret_cast<bf16x8*>(smem);
+    bf16x8* sB = reinterpret_cast<bf16x8*>(smem + 2 * BM * BK * 2);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t M = (int64_t)a.B * a.OD * a.OH * a.OW;
+    const int64_t m0 = (int64_t)blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    const int srow = tid >> 3, schunk = tid & 7;
+
+    // per staged row: base voxel coordinates of the receptive field
+    int rb[PA], rd[PA], rh[PA], rw[PA];
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        int64_t m = m0 + srow + 32 * p;
+        if (m >= M) m = M - 1;
+        const int ow = (int)(m % a.OW);
+        int64_t r = m / a.OW;
+        const int oh = (int)(r % a.OH); r /= a.OH;
+        const int od = (int)(r % a.OD);
+        rb[p] = (int)(r / a.OD);
+        rd[p] = od * a.stride - a.pad; rh[p] = oh * a.stride - a.pad; rw[p] = ow * a.stride - a.pad;
+    }
+    const bf16* gB[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        int r = n0 + srow + 32 * p;
+        r = r < a.Cout ? r : a.Cout - 1;
+        gB[p] = a.w + (int64_t)r * 27 * a.Cin + schunk * 8;
+    }
+    const int cpk = a.Cin / BK;                 // K-steps per tap
+    const int nk = 27 * cpk;
+    bf16x8 rA[PA], rB[PB];
+    auto load_tile = [&](int kt) {
+        const int tap = kt / cpk, c0 = (kt - tap * cpk) * BK;
+        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const int id = rd[p] + kd, ih = rh[p] + kh, iw = rw[p] + kw;
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (bf16)0.f;
+            if ((unsigned)id < (unsigned)a.ID && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW)
+                v = *reinterpret_cast<const bf16x8*>(a.in + ((((int64_t)rb[p] * a.ID + id) * a.IH + ih) * a.IW + iw) * a.Cin + c0 + schunk * 8);
+            rA[p] = v;
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) rB[p] = *reinterpret_cast<const bf16x8*>(gB[p] + (int64_t)kt * BK);
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const int r = srow + 32 * p;
+            sA[(buf * BM + r) * 8 + (schunk ^ (r & 7))] = rA[p];
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const int r = srow + 32 * p;
+            sB[(buf * BN + r) * 8 + (schunk ^ (r & 7))] = rB[p];
+        }
+    };
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[MT], fb[NT];
+            const int chunk = kk * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int r = wm * (BM / 2) + i * 16 + fr;
+                fa[i] = sA[(buf * BM + r) * 8 + (chunk ^ (r & 7))];
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int r = wn * (BN / 2) + j * 16 + fr;
+                fb[j] = sB[(buf * BN + r) * 8 + (chunk ^ (r & 7))];
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int64_t m = m0 + wm * (BM / 2) + i * 16 + fr;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 16 + 4 * fq;
+            if (n >= a.Cout) continue;
+            const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+            f32x4 v = acc[i][j];
+            float4 o = make_float4(v[0] + b.x, v[1] + b.y, v[2] + b.z, v[3] + b.w);
+            if (a.resid) {
+                const float4 r = *reinterpret_cast<const float4*>(a.resid + m * a.Cout + n);
+                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            }
+            *reinterpret_cast<float4*>(a.out + m * a.Cout + n) = o;
+        }
+    }
+}
+
+// tokens[b][t][c] = z[b][t][:].Wp[c][:] + bp[c] + r_emb[r][c] + a_emb[a][c] + e_emb[e][c], t = (r*A + a)*E + e
+__global__ void radar_token_kernel(const float* __restrict__ z, const float* __restrict__ Wp, const float* __restrict__ bp,
+                                   const float* __restrict__ re, const float* __restrict__ ae, const float* __restrict__ ee,
+                                   float* __restrict__ tok, int R, int A, int E, int zc, int C) {
+    const int t = blockIdx.x;                 // token within the batch
+    const int b = blockIdx.y;
+    const int e = t % E, aa = (t / E) % A, r = t / (E * A);
+    const float* zz = z + ((int64_t)b * R * A * E + t) * zc;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc = bp[c];
+        for (int k = 0; k < zc; ++k) acc += zz[k] * Wp[c * zc + k];
+        tok[((int64_t)b * R * A * E + t) * C + c] = acc + re[r * C + c] + ae[aa * C + c] + ee[e * C + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct RadarEncoder::Impl {
+    int ch = 64, zc = 16, R = 128, A = 64, E = 32, token_ch = 512;
+    DeviceArena* arena = nullptr;
+    enum Kind { CONV3, CONV1, VEC, CONVIN };
+    struct Tensor { Kind kind; int cout, cin; void* ptr = nullptr; bool loaded = false; };
+    std::map<std::string, Tensor> tensors;
+    // tokeniser
+    float *w_tok = nullptr, *b_tok = nullptr, *emb_r = nullptr, *emb_a = nullptr, *emb_e = nullptr;
+    bool tok_loaded[5] = {false, false, false, false, false};
+    // workspace (for `sub` samples at a time)
+    int sub = 0;
+    float *f0 = nullptr, *f1 = nullptr, *f2 = nullptr, *z = nullptr, *tok = nullptr, *sbuf = nullptr;
+    bf16 *n16 = nullptr, *q16 = nullptr, *k16 = nullptr, *vt16 = nullptr, *p16 = nullptr, *o16 = nullptr;
+    double* stats = nullptr;
+    int tok_batch = 0;
+
+    void add(const std::string& name, Kind k, int cout, int cin) { tensors[name] = Tensor{k, cout, cin}; }
+    void add_conv3(const std::string& n, int cout, int cin) { add(n + ".weight", CONV3, cout, cin); add(n + ".bias", VEC, cout, 0); }
+    void add_conv1(const std::string& n, int cout, int cin) { add(n + ".weight", CONV1, cout, cin); add(n + ".bias", VEC, cout, 0); }
+    void add_norm(const std::string& n, int c) { add(n + ".weight", VEC, c, 0); add(n + ".bias", VEC, c, 0); }
+    void add_res(const std::string& n, int cin, int cout) {
+        add_norm(n + ".norm1", cin); add_conv3(n + ".conv1", cout, cin); add_norm(n + ".norm2", cout); add_conv3(n + ".conv2", cout, cout);
+        if (cin != cout) add_conv1(n + ".nin_shortcut", cout, cin);
+    }
+    void add_attn(const std::string& n, int c) {
+        add_norm(n + ".norm", c);
+        for (const char* p : {".q", ".k", ".v", ".proj_out"}) add_conv1(n + p, c, c);
+    }
+    template <class T> T* P(const std::string& n) { return (T*)tensors.at(n).ptr; }
+
+    int ensure_ws(int nsub);
+    int run_conv(const bf16* in, const std::string& name, const float* resid, float* out, int B, int ID, int IH, int IW, int cin,
+                 int cout, int stride, int pad, hipStream_t st);
+    int gn(const float* x, const std::string& name, bf16* y, int B, int S, int C, bool swish, hipStream_t st);
+    int resblock(float*& x, float*& t1, float*& t2, const std::string& name, int B, int Dd, int Hh, int Ww, int cin, int cout, hipStream_t st);
+    int attnblock(float* x, const std::string& name, int B, int S, int C, hipStream_t st);
+    int forward(const float* cube, int cube_ch, int B, float* zout, hipStream_t st);
+};
+
+static const int kChMult[5] = {1, 1, 2, 2, 4};
+
+int RadarEncoder::create(int ch, int z_ch, int R, int A, int E, int token_ch, DeviceArena* arena) {
+    RALD_CHECK(ch % 64 == 0 && ch >= 64, "radar encoder: hidden channels must be a multiple of 64");
+    RALD_CHECK(R % 16 == 0 && A % 16 == 0 && E % 16 == 0, "radar encoder: cube dims must be multiples of 16");
+    RALD_CHECK(z_ch % 4 == 0 && z_ch <= 64, "radar encoder: z channels must be a multiple of 4, <= 64");
+    impl = new Impl();
+    Impl& m = *impl;
+    m.ch = ch; m.zc = z_ch; m.R = R; m.A = A; m.E = E; m.token_ch = token_ch; m.arena = arena;
+    m.add("conv_in.weight", Impl::CONVIN, ch, 1);
+    m.add("conv_in.bias", Impl::VEC, ch, 0);
+    int block_in = ch;
+    for (int l = 0; l < 5; ++l) {
+        const int block_out = ch * kChMult[l];
+        block_in = ch * (l == 0 ? 1 : kChMult[l - 1]);
+        for (int b = 0; b < 2; ++b) {
+            m.add_res("down." + std::to_string(l) + ".block." + std::to_string(b), block_in, block_out);
+            block_in = block_out;
+        }
+        if (l == 4)
+            for (int b = 0; b < 2; ++b) m.add_attn("down.4.attn." + std::to_string(b), block_in);
+        if (l != 4) m.add_conv3("down." + std::to_string(l) + ".downsample.conv", block_in, block_in);
+    }
+    m.add_res("mid.block_1", block_in, block_in);
+    m.add_attn("mid.attn_1", block_in);
+    m.add_res("mid.block_2", block_in, block_in);
+    m.add_norm("norm_out", block_in);
+    m.add_conv3("conv_out", z_ch, block_in);
+    for (auto& kv : m.tensors) {
+        auto& t = kv.second;
+        size_t bytes = 0;
+        switch (t.kind) {
+            case Impl::CONV3: bytes = (size_t)t.cout * 27 * t.cin * 2; break;
+            case Impl::CONV1: bytes = (size_t)t.cout * t.cin * 2; break;
+            case Impl::VEC: bytes = (size_t)t.cout * 4; break;
+            case Impl::CONVIN: bytes = (size_t)t.cout * 27 * 4; break;
+        }
+        t.ptr = arena->alloc(bytes < 64 ? 64 : bytes, true);       // >= 16 floats so float4 bias reads of a 16-ch tail stay in bounds
+        RALD_CHECK(t.ptr, "radar encoder: weight allocation failed");
+    }
+    const int nt_r = R / 16, nt_a = A / 16, nt_e = E / 16;
+    m.w_tok = (float*)arena->alloc((size_t)token_ch * z_ch * 4, true);
+    m.b_tok = (float*)arena->alloc((size_t)token_ch * 4, true);
+    m.emb_r = (float*)arena->alloc((size_t)nt_r * token_ch * 4, true);
+    m.emb_a = (float*)arena->alloc((size_t)nt_a * token_ch * 4, true);
+    m.emb_e = (float*)arena->alloc((size_t)nt_e * token_ch * 4, true);
+    RALD_CHECK(m.w_tok && m.b_tok && m.emb_r && m.emb_a && m.emb_e, "radar encoder: allocation failed");
+    return 0;
+}
+
+void RadarEncoder::expected_keys(const std::string& prefix, std::set<std::string>& out) const {
+    if (!impl) return;
+    for (const auto& kv : impl->tensors) out.insert(prefix + kv.first);
+}
+
+int RadarEncoder::load_weight(const std::string& name, const float* data, int64_t nelem, Stager& st) {
+    RALD_CHECK(impl, "radar encoder: not created");
+    auto it = impl->tensors.find(name);
+    RALD_CHECK(it != impl->tensors.end(), "radar encoder: unknown key '" + name + "'");
+    auto& t = it->second;
+    switch (t.kind) {
+        case Impl::VEC:
+            RALD_CHECK(nelem == t.cout, "radar encoder: size mismatch for '" + name + "'");
+            RALD_TRY(st.to_f32(data, (float*)t.ptr, 1, t.cout, t.cout, nullptr));
+            break;
+        case Impl::CONVIN:
+            RALD_CHECK(nelem == (int64_t)t.cout * 27, "radar encoder: size mismatch for '" + name + "'");
+            RALD_TRY(st.to_f32(data, (float*)t.ptr, t.cout, 27, 27, nullptr));
+            break;
+        case Impl::CONV1:
+            RALD_CHECK(nelem == (int64_t)t.cout * t.cin, "radar encoder: size mismatch for '" + name + "'");
+            RALD_TRY(st.to_bf16(data, (bf16*)t.ptr, t.cout, t.cin, t.cin, nullptr));
+            break;
+        case Impl::CONV3: {
+            RALD_CHECK(nelem == (int64_t)t.cout * t.cin * 27, "radar encoder: size mismatch for '" + name + "'");
+            // torch [Cout][Cin][3][3][3] -> [Cout][tap][Cin] (host permute, then bf16 upload)
+            std::vector<float> src((size_t)nelem), dst((size_t)nelem);
+            RALD_HIP(hipMemcpy(src.data(), data, (size_t)nelem * 4, hipMemcpyDefault));
+            for (int co = 0; co < t.cout; ++co)
+                for (int ci = 0; ci < t.cin; ++ci)
+                    for (int tp = 0; tp < 27; ++tp)
+                        dst[((size_t)co * 27 + tp) * t.cin + ci] = src[((size_t)co * t.cin + ci) * 27 + tp];
+            RALD_TRY(st.to_bf16(dst.data(), (bf16*)t.ptr, t.cout * 27, t.cin, t.cin, nullptr));
+            break;
+        }
+    }
+    t.loaded = true;
+    return 0;
+}
+
+int RadarEncoder::load_token_weight(const std::string& name, const float* data, int64_t nelem, Stager& st) {
+    RALD_CHECK(impl, "radar encoder: not created");
+    Impl& m = *impl;
+    const int C = m.token_ch;
+    if (name == "radar_token_project.weight") { RALD_CHECK(nelem == (int64_t)C * m.zc, "size mismatch: " + name); m.tok_loaded[0] = true; return st.to_f32(data, m.w_tok, C, m.zc, m.zc, nullptr); }
+    if (name == "radar_token_project.bias") { RALD_CHECK(nelem == C, "size mismatch: " + name); m.tok_loaded[1] = true; return st.to_f32(data, m.b_tok, 1, C, C, nullptr); }
+    if (name == "radar_r_emb.weight") { RALD_CHECK(nelem == (int64_t)(m.R / 16) * C, "size mismatch: " + name); m.tok_loaded[2] = true; return st.to_f32(data, m.emb_r, m.R / 16, C, C, nullptr); }
+    if (name == "radar_a_emb.weight") { RALD_CHECK(nelem == (int64_t)(m.A / 16) * C, "size mismatch: " + name); m.tok_loaded[3] = true; return st.to_f32(data, m.emb_a, m.A / 16, C, C, nullptr); }
+    if (name == "radar_e_emb.weight") { RALD_CHECK(nelem == (int64_t)(m.E / 16) * C, "size mismatch: " + name); m.tok_loaded[4] = true; return st.to_f32(data, m.emb_e, m.E / 16, C, C, nullptr); }
+    RALD_CHECK(false, "radar encoder: unknown key '" + name + "'");
+}
+
+int RadarEncoder::Impl::ensure_ws(int nsub) {
+    if (nsub <= sub) return 0;
+    RALD_HIP(hipDeviceSynchronize());
+    for (void* p : {(void*)f0, (void*)f1, (void*)f2, (void*)n16, (void*)stats, (void*)q16, (void*)k16, (void*)vt16, (void*)p16, (void*)o16, (void*)sbuf})
+        if (p) arena->release(p);
+    const size_t vox = (size_t)R * A * E;
+    const size_t act = (size_t)nsub * vox * ch;                 // level-0 activation (the largest)
+    const int ntok = (R / 16) * (A / 16) * (E / 16), cl = ch * 4;
+    f0 = (float*)arena->alloc(act * 4, true);
+    f1 = (float*)arena->alloc(act * 4, true);
+    f2 = (float*)arena->alloc(act * 4, true);
+    n16 = (bf16*)arena->alloc(act * 2, true);
+    stats = (double*)arena->alloc((size_t)nsub * 32 * 2 * 8, true);
+    q16 = (bf16*)arena->alloc((size_t)nsub * ntok * cl * 2, true);
+    k16 = (bf16*)arena->alloc((size_t)nsub * ntok * cl * 2, true);
+    vt16 = (bf16*)arena->alloc((size_t)nsub * cl * ntok * 2, true);
+    p16 = (bf16*)arena->alloc((size_t)nsub * ntok * ntok * 2, true);
+    o16 = (bf16*)arena->alloc((size_t)nsub * ntok * cl * 2, true);
+    sbuf = (float*)arena->alloc((size_t)nsub * ntok * ntok * 4, true);
+    RALD_CHECK(f0 && f1 && f2 && n16 && stats && q16 && k16 && vt16 && p16 && o16 && sbuf, "radar encoder: workspace allocation failed");
+    sub = nsub;
+    return 0;
+}
+
+int RadarEncoder::Impl::gn(const float* x, const std::string& name, bf16* y, int B, int S, int C, bool swish, hipStream_t st) {
+    RALD_HIP(hipMemsetAsync(stats, 0, (size_t)B * 32 * 2 * 8, st));
+    const int vpb = 2048;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(cdiv(S, vpb), B), dim3(256), 0, st, x, stats, S, C, vpb);
+    const int64_t quads = (int64_t)S * C / 4;
+    const int blocks = (int)((quads + 255) / 256 < 1024 ? (quads + 255) / 256 : 1024);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, B), dim3(256), 0, st, x, stats, P<float>(name + ".weight"), P<float>(name + ".bias"), y,
+                       S, C, 1e-6f, swish ? 1 : 0);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+int RadarEncoder::Impl::run_conv(const bf16* in, const std::string& name, const float* resid, float* out, int B, int ID, int IH,
+                                 int IW, int cin, int cout, int stride, int pad, hipStream_t st) {
+    ConvArgs a;
+    a.in = in; a.w = P<bf16>(name + ".weight"); a.bias = P<float>(name + ".bias"); a.resid = resid; a.out = out;
+    a.B = B; a.ID = ID; a.IH = IH; a.IW = IW; a.Cin = cin; a.Cout = cout; a.stride = stride; a.pad = pad;
+    a.OD = ID / stride; a.OH = IH / stride; a.OW = IW / stride;
+    RALD_CHECK(cin % 64 == 0 && cout % 4 == 0, "conv3d: Cin must be a multiple of 64 and Cout of 4");
+    const int64_t M = (int64_t)B * a.OD * a.OH * a.OW;
+    hipLaunchKernelGGL(conv3d_igemm_kernel, dim3(cdiv(cout, 64), (unsigned)((M + 127) / 128)), dim3(256), 0, st, a);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ResnetBlock.forward (:82-100): x -> x + conv2(swish(GN(conv1(swish(GN(x)))))), 1x1 shortcut if channels change.
+int RadarEncoder::Impl::resblock(float*& x, float*& t1, float*& t2, const std::string& name, int B, int Dd, int Hh, int Ww, int cin,
+                                 int cout, hipStream_t st) {
+    const int S = Dd * Hh * Ww;
+    RALD_TRY(gn(x, name + ".norm1", n16, B, S, cin, true, st));
+    RALD_TRY(run_conv(n16, name + ".conv1", nullptr, t1, B, Dd, Hh, Ww, cin, cout, 1, 1, st));
+    const float* res = x;
+    if (cin != cout) {
+        RALD_TRY(cast_f32_bf16(x, n16, (int64_t)B * S * cin, st));
+        GemmArgs g = gemm_args(n16, cin, P<bf16>(name + ".nin_shortcut.weight"), cin, t2, cout, P<float>(name + ".nin_shortcut.bias"), B * S, cout, cin);
+        RALD_TRY(gemm_nt(g, EPI_F32, st));
+        res = t2;
+    }
+    RALD_TRY(gn(t1, name + ".norm2", n16, B, S, cout, true, st));
+    float* dst = (cin != cout) ? t2 : x;                       // in-place residual add (same index read then written)
+    RALD_TRY(run_conv(n16, name + ".conv2", res, dst, B, Dd, Hh, Ww, cout, cout, 1, 1, st));
+    if (cin != cout) std::swap(x, t2);
+    return 0;
+}
+
+// AttnBlock.forward (:112-135): single head over the S tokens, scale C^-1/2, residual.
+int RadarEncoder::Impl::attnblock(float* x, const std::string& name, int B, int S, int C, hipStream_t st) {
+    RALD_CHECK(S % 64 == 0, "radar attention: token count must be a multiple of 64");
+    RALD_TRY(gn(x, name + ".norm", n16, B, S, C, false, st));
+    GemmArgs q = gemm_args(n16, C, P<bf16>(name + ".q.weight"), C, q16, C, P<float>(name + ".q.bias"), B * S, C, C);
+    RALD_TRY(gemm_nt(q, EPI_BF16, st));
+    GemmArgs k = gemm_args(n16, C, P<bf16>(name + ".k.weight"), C, k16, C, P<float>(name + ".k.bias"), B * S, C, C);
+    RALD_TRY(gemm_nt(k, EPI_BF16, st));
+    GemmArgs v = gemm_args(P<bf16>(name + ".v.weight"), C, n16, C, vt16, S, nullptr, C, S, C);   // V^T (bias folded below)
+    v.batch = B; v.strideB = (int64_t)S * C; v.strideC = (int64_t)C * S;
+    RALD_TRY(gemm_nt(v, EPI_BF16, st));
+    GemmArgs s = gemm_args(q16, C, k16, C, sbuf, S, nullptr, S, S, C);
+    s.batch = B; s.strideA = (int64_t)S * C; s.strideB = (int64_t)S * C; s.strideC = (int64_t)S * S; s.alpha = 1.0f / sqrtf((float)C);
+    RALD_TRY(gemm_nt(s, EPI_F32, st));
+    RALD_TRY(softmax_rows(sbuf, S, p16, S, B * S, S, st));
+    // rows of P sum to 1, so P.(v + 1.b_v^T) = P.v + b_v: the v bias becomes the epilogue bias
+    GemmArgs pv = gemm_args(p16, S, vt16, S, o16, C, P<float>(name + ".v.bias"), S, C, S);
+    pv.batch = B; pv.strideA = (int64_t)S * S; pv.strideB = (int64_t)C * S; pv.strideC = (int64_t)S * C;
+    RALD_TRY(gemm_nt(pv, EPI_BF16, st));
+    GemmArgs o = gemm_args(o16, C, P<bf16>(name + ".proj_out.weight"), C, x, C, P<float>(name + ".proj_out.bias"), B * S, C, C);
+    RALD_TRY(gemm_nt(o, EPI_RESID, st));
+    return 0;
+}
+
+int RadarEncoder::Impl::forward(const float* cube, int cube_ch, int B, float* zout, hipStream_t st) {
+    for (const auto& kv : tensors) RALD_CHECK(kv.second.loaded, "radar encoder: missing key '" + kv.first + "'");
+    RALD_TRY(ensure_ws(B));
+    float *x = f0, *t1 = f1, *t2 = f2;
+    int Dd = R, Hh = A, Ww = E;
+    {
+        const int groups = ch / 8, vpb = 256 / groups;
+        const int64_t nvox = (int64_t)B * Dd * Hh * Ww;
+        hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)((nvox + vpb - 1) / vpb)), dim3(256), 27 * ch * 4, st, cube, cube_ch,
+                           P<float>("conv_in.weight"), P<float>("conv_in.bias"), x, B, Dd, Hh, Ww, ch);
+        RALD_HIP(hipGetLastError());
+    }
+    int cin = ch;
+    for (int l = 0; l < 5; ++l) {
+        const int cout = ch * kChMult[l];
+        for (int b = 0; b < 2; ++b) {
+            const std::string nm = "down." + std::to_string(l) + ".block." + std::to_string(b);
+            RALD_TRY(resblock(x, t1, t2, nm, B, Dd, Hh, Ww, cin, cout, st));
+            cin = cout;
+            if (l == 4) RALD_TRY(attnblock(x, "down.4.attn." + std::to_string(b), B, Dd * Hh * Ww, cin, st));
+        }
+        if (l != 4) {
+            // Downsample (:37-41): input is the raw trunk (no norm/activation), cast to bf16
+            RALD_TRY(cast_f32_bf16(x, n16, (int64_t)B * Dd * Hh * Ww * cin, st));
+            RALD_TRY(run_conv(n16, "down." + std::to_string(l) + ".downsample.conv", nullptr, t1, B, Dd, Hh, Ww, cin, cin, 2, 0, st));
+            std::swap(x, t1);
+            Dd /= 2; Hh /= 2; Ww /= 2;
+        }
+    }
+    RALD_TRY(resblock(x, t1, t2, "mid.block_1", B, Dd, Hh, Ww, cin, cin, st));
+    RALD_TRY(attnblock(x, "mid.attn_1", B, Dd * Hh * Ww, cin, st));
+    RALD_TRY(resblock(x, t1, t2, "mid.block_2", B, Dd, Hh, Ww, cin, cin, st));
+    RALD_TRY(gn(x, "norm_out", n16, B, Dd * Hh * Ww, cin, true, st));
+    RALD_TRY(run_conv(n16, "conv_out", nullptr, zout, B, Dd, Hh, Ww, cin, zc, 1, 1, st));
+    return 0;
+}
+
+int RadarEncoder::encode(const float* cube, int cube_ch, int B, float** zptr, hipStream_t st) {
+    RALD_CHECK(impl && cube && B >= 1, "radar encoder: bad arguments");
+    Impl& m = *impl;
+    const int ntok = (m.R / 16) * (m.A / 16) * (m.E / 16);
+    if (B > m.tok_batch) {
+        RALD_HIP(hipDeviceSynchronize());
+        if (m.z) m.arena->release(m.z);
+        if (m.tok) m.arena->release(m.tok);
+        m.z = (float*)m.arena->alloc((size_t)B * ntok * m.zc * 4, true);
+        m.tok = (float*)m.arena->alloc((size_t)B * ntok * m.token_ch * 4, true);
+        RALD_CHECK(m.z && m.tok, "radar encoder: allocation failed");
+        m.tok_batch = B;
+    }
+    const int SUB = 4;                                         // samples per pass: bounds the 67 MB/sample fp32 trunk buffers
+    const size_t cube_stride = (size_t)m.R * m.A * m.E * cube_ch;
+    for (int b0 = 0; b0 < B; b0 += SUB) {
+        const int nb = B - b0 < SUB ? B - b0 : SUB;
+        RALD_TRY(m.forward(cube + (size_t)b0 * cube_stride, cube_ch, nb, m.z + (size_t)b0 * ntok * m.zc, st));
+    }
+    *zptr = m.z;
+    return 0;
+}
+
+int RadarEncoder::tokens(const float* cube, int B, float** tokens_out, hipStream_t st) {
+    RALD_CHECK(impl, "radar encoder: not created");
+    Impl& m = *impl;
+    for (int i = 0; i < 5; ++i) RALD_CHECK(m.tok_loaded[i], "radar encoder: tokeniser weights missing");
+    float* z = nullptr;
+    RALD_TRY(encode(cube, 2, B, &z, st));                      // intensity channel of the [.,2] cube (:378)
+    const int nr = m.R / 16, na = m.A / 16, ne = m.E / 16;
+    hipLaunchKernelGGL(radar_token_kernel, dim3(nr * na * ne, B), dim3(256), 0, st, z, m.w_tok, m.b_tok, m.emb_r, m.emb_a, m.emb_e, m.tok, nr,
+                       na, ne, m.zc, m.token_ch);
+    RALD_HIP(hipGetLastError());
+    *tokens_out = m.tok;
+    return 0;
+}
+
 RadarEncoder::~RadarEncoder() { delete impl; }
+
 }  // namespace rald
