@@ -100,8 +100,27 @@ def cpu_baseline_nfe(sd, depth, seconds_budget=20.0):
             O.latent_transformer(sd, x, t, cond, depth=depth)
             reps += 1
         dt = time.perf_counter() - t0
-    return {"value": B * reps / dt, "unit": "sample*NFE/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} NFEs of the fp32 oracle at B={B} (same weights/shapes), torch CPU {cores} threads"}
+    res = {"value": B * reps / dt, "unit": "sample*NFE/s", "cores": cores, "kind": "port",
+           "sample": f"{reps} NFEs of the fp32 oracle at B={B} (same weights/shapes), torch CPU {cores} threads"}
+    # AE encode / decode on the same host cores (one warm-up + 2 reps each, P = Q = 10 000, B = 1)
+    try:
+        from rald_amd import weights
+        sd_ae = weights.make_state_dict(weights.ae_spec(), 0)
+        pc, q, eps = synth.point_cloud(1, 10000), synth.queries(1, 10000), synth.normal([1, 512, 32], 3)
+        with torch.no_grad():
+            _, z, _, _ = O.ae_encode(sd_ae, pc, eps)
+            t0 = time.perf_counter()
+            for _ in range(2):
+                O.ae_encode(sd_ae, pc, eps)
+            res["ae_encode_ms"] = (time.perf_counter() - t0) / 2 * 1e3
+            O.ae_decode(sd_ae, z, q, depth=24)
+            t0 = time.perf_counter()
+            for _ in range(2):
+                O.ae_decode(sd_ae, z, q, depth=24)
+            res["ae_decode_10k_ms"] = (time.perf_counter() - t0) / 2 * 1e3
+    except Exception as e:
+        res["ae_error"] = repr(e)
+    return res
 
 
 def main():

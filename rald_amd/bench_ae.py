@@ -1,0 +1,52 @@
+"""AE encode / decode latency (BASELINE.json configs[1]: full VecSet AE, kl_d512_m512_l32_mix,
+P = 10 000 points; decode at Q = 10 000 and 1 200 000 queries) on synthetic view-cone clouds."""
+from __future__ import annotations
+
+import time
+
+import torch
+
+from . import models_ae as A
+from . import synth, weights
+
+
+def _time(fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def build_ae():
+    m = A.kl_d512_m512_l32_mix(N=10000)
+    m.load_state_dict(weights.make_state_dict(weights.ae_spec(), 0))
+    return m.cuda()
+
+
+def run(batches=(1, 8)) -> dict:
+    out = {}
+    m = build_ae()
+    h = m._handle()
+    for B in batches:
+        pc = synth.point_cloud(B, 10000).cuda()
+        eps = synth.normal([B, 512, 32], 3).cuda()
+        out[f"ae_encode_ms_B{B}"] = _time(lambda: h.encode(pc, eps))
+        z = h.encode(pc, eps)[1]
+        out[f"ae_decode_latents_ms_B{B}"] = _time(lambda: h.decode_latents(z))
+        ctx = h.decode_latents(z)
+        q10k = synth.queries(B, 10000).cuda()
+        out[f"ae_decode_queries_10k_ms_B{B}"] = _time(lambda: h.decode_queries(ctx, q10k))
+        # what the reference's decode(z, queries) costs as one call (stack + queries), Q = 10 000
+        out[f"ae_decode_10k_ms_B{B}"] = out[f"ae_decode_latents_ms_B{B}"] + out[f"ae_decode_queries_10k_ms_B{B}"]
+    B = 1
+    z = h.encode(synth.point_cloud(1, 10000).cuda(), synth.normal([1, 512, 32], 3).cuda())[1]
+    ctx = h.decode_latents(z)
+    q = synth.queries(1, 1200000).cuda()
+    ms = _time(lambda: h.decode_queries(ctx, q), reps=3, warm=1)
+    out["ae_decode_queries_1200k_ms_B1"] = ms
+    out["ae_decode_queries_Mq_per_s"] = 1.2e6 / ms / 1e3
+    return out
