@@ -1,0 +1,50 @@
+"""The ~15 lines of the reference's generation engine that call the hot path
+(engine_generation.py:183-232, :274-300), restated as a batch-sharded driver: radar cube ->
+EDMPrecond.sample -> vae.decode on query sets -> occupancy = logits > 0.  Data loading, PLY
+writing and Chamfer metrics are out of scope."""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional, Sequence
+
+import torch
+
+from . import distributed as D
+
+
+@torch.no_grad()
+def sample_and_decode(model, vae, radar_cube: torch.Tensor, query_sets: Sequence[torch.Tensor],
+                      batch_seeds: Optional[torch.Tensor] = None) -> Dict[str, object]:
+    """One evaluation batch on ONE rank: `model.sample` (18 Heun steps, condition encoded once),
+    then every query set decoded against the same latents (the 24-layer latent stack runs once:
+    rald_amd.models_ae memoises the decoder context per latent tensor).
+    Returns {'latents': [B,512,C], 'logits': [ [B,Q_i] ... ], 'occupied': [bool masks]}."""
+    sampled = model.sample(cond=radar_cube, batch_seeds=batch_seeds, cond_type='radar')        # :195
+    logits = [vae.decode(sampled, q).squeeze(-1) for q in query_sets]                          # :204, :275, :300
+    return {"latents": sampled, "logits": logits, "occupied": [l > 0 for l in logits]}        # :229-232
+
+
+@torch.no_grad()
+def evaluate_sharded(model, vae, cubes: torch.Tensor, queries: torch.Tensor, eval_batch_size: int = 1,
+                     metric_fn: Optional[Callable[[torch.Tensor, int], float]] = None) -> Dict[str, float]:
+    """Batch-sharded evaluation: every rank owns the samples DistributedSampler would give it,
+    runs them in eval batches with seeds = global sample index, and the only collective is the
+    final metric reduction (utils/misc.py:45-47).  `cubes` [N,R,A,E,2] and `queries` [N,Q,3] are the
+    full (host) arrays; each rank moves only its shard to the device."""
+    rank = torch.distributed.get_rank() if D.is_dist() else 0
+    world = D.world_size()
+    mine = D.shard_sample_indices(cubes.shape[0], rank, world)
+    total, count = 0.0, 0.0
+    occupied_fraction = []
+    dev = next(model.parameters()).device
+    for i in range(0, len(mine), eval_batch_size):
+        idx = mine[i:i + eval_batch_size]
+        out = sample_and_decode(model, vae, cubes[idx].to(dev), [queries[idx].to(dev)],
+                                batch_seeds=torch.tensor(idx))
+        occ = out["occupied"][0].float().mean(dim=1)
+        for j, gi in enumerate(idx):
+            val = metric_fn(out["logits"][0][j], gi) if metric_fn else float(occ[j])
+            total += val
+            count += 1
+            occupied_fraction.append(float(occ[j]))
+    total, count = D.reduce_sum_count(total, count)
+    return {"metric_mean": total / max(count, 1.0), "n_samples": count}
