@@ -1,4 +1,6 @@
 // extern "C" surface of librald_hip.so (include/rald_hip.h).  Thin: argument checks + dispatch.
+#include <cstdlib>
+
 #include "ae.h"
 #include "dit.h"
 
@@ -116,7 +118,8 @@ int rald_op_gemm_nt(const void* A, int64_t lda, int64_t strideA, const void* B, 
     RALD_CHECK(A && B && C, "rald_op_gemm_nt: null pointer");
     GemmArgs g;
     g.A = (const bf16*)A; g.lda = lda; g.strideA = strideA; g.B = (const bf16*)B; g.ldb = ldb; g.strideB = strideB;
-    g.C = C; g.ldc = ldc; g.strideC = strideC; g.bias = bias; g.M = M; g.N = N; g.K = K; g.batch = batch; g.alpha = alpha;
+    g.C = C; g.ldc = ldc; g.strideC = strideC; g.bias = bias; g.M = M; g.N = N; g.K = K; g.batch = batch; g.alpha = alpha; g.ablate = 0;
+    if (const char* e = getenv("RALD_GEMM_ABLATE")) g.ablate = atoi(e);
     return gemm_nt(g, epilogue, (hipStream_t)stream);
 }
 int rald_op_layernorm(const float* x, void* out_bf16, int32_t M, int32_t D, const float* g, const float* b,

@@ -4,10 +4,15 @@
 //   torch.nn.Linear stores them) - both K-contiguous, which is exactly the MFMA fragment
 //   order, so neither operand is ever transposed in memory.
 //
-// Tile: BM x BN x 64, 256 threads = 4 waves as 2x2, each wave (BM/2)x(BN/2) in 16x16 MFMA
-// tiles.  Staging: global_load_dwordx4 -> registers -> ds_write_b128 into a double-buffered
-// LDS image whose 16-byte chunks are XOR-swizzled by (row & 7) (128-byte rows would
-// otherwise put every ds_read_b128 lane group on two 16-byte slots of the 256-byte bank row).
+// Two staging engines share one tile/epilogue design (BM x BN x 64, waves in a 2 x (WAVES/2) grid,
+// 16x16 MFMA tiles, LDS rows of 128 B whose 16-byte chunks are XOR-swizzled by (row & 7) so every
+// ds_read_b128 lane group is bank-conflict free):
+//   * gemm_nt_kernel      register staging: global_load_dwordx4 -> VGPR -> ds_write_b128.  At 2
+//                         workgroups/CU the ds_write path (~79 B/clk/CU) makes this LDS-bound.
+//   * gemm_nt_glds_kernel LDS-DMA staging: global_load_lds_dwordx4 writes the tile straight into
+//                         LDS (lane-linear destination; the swizzle is applied to each lane's
+//                         SOURCE address and again on the read - CDNA guide rule 21), freeing the
+//                         ds_write bandwidth and 32 staging VGPRs.
 // The MFMA is issued with the weight fragment as the "A" operand so each lane ends up owning
 // 4 CONSECUTIVE output columns of one row (D[i=n][j=m]: j = lane&15, i = 4*(lane>>4)+reg):
 // the epilogue stores 8-byte (bf16) / 16-byte (f32) pieces instead of 2-byte scatters.
@@ -19,11 +24,142 @@
 //   EPI_GEGLU  C_bf16[m][c] = (acc_x + b_x) * gelu_erf(acc_g + b_g)   weights pre-packed so that
 //              packed rows [32t,32t+16) are the 'x' half and [32t+16,32t+32) the 'gate' half of
 //              output columns [16t,16t+16)  (models_radar_generation.py:93-95, models_ae.py:52-54)
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
 namespace rald {
 
+// ---- epilogue: lane owns row m = mb + 16i + fr, 4 consecutive columns n = nb + 16j + 4*fq + {0..3}
+template <int MT, int NT, int EPI>
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NT], const GemmArgs& a, int mb, int nb, int bz, int fr, int fq) {
+    if constexpr (EPI == EPI_GEGLU) {
+        bf16* C = reinterpret_cast<bf16*>(a.C) + (int64_t)bz * a.strideC;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = mb + i * 16 + fr;
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int p = 0; p < NT / 2; ++p) {
+                const int nx = nb + 32 * p + 4 * fq;           // packed row of the 'x' half
+                const int ng = nx + 16;                        // packed row of the gate half
+                float4 bx = *reinterpret_cast<const float4*>(a.bias + nx);
+                float4 bg = *reinterpret_cast<const float4*>(a.bias + ng);
+                f32x4 x = acc[i][2 * p], g = acc[i][2 * p + 1];
+                bf16x4 o = pack4((x[0] + bx.x) * gelu_erf(g[0] + bg.x), (x[1] + bx.y) * gelu_erf(g[1] + bg.y),
+                                 (x[2] + bx.z) * gelu_erf(g[2] + bg.z), (x[3] + bx.w) * gelu_erf(g[3] + bg.w));
+                const int c = nb / 2 + 16 * p + 4 * fq;
+                *reinterpret_cast<bf16x4*>(C + (int64_t)m * a.ldc + c) = o;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = mb + i * 16 + fr;
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = nb + j * 16 + 4 * fq;
+                if (n >= a.N) continue;                        // N is a multiple of 4
+                f32x4 v = acc[i][j];
+                float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.bias) b = *reinterpret_cast<const float4*>(a.bias + n);
+                if constexpr (EPI == EPI_BF16) {
+                    bf16* C = reinterpret_cast<bf16*>(a.C) + (int64_t)bz * a.strideC;
+                    *reinterpret_cast<bf16x4*>(C + (int64_t)m * a.ldc + n) =
+                        pack4(a.alpha * v[0] + b.x, a.alpha * v[1] + b.y, a.alpha * v[2] + b.z, a.alpha * v[3] + b.w);
+                } else if constexpr (EPI == EPI_F32) {
+                    float* C = reinterpret_cast<float*>(a.C) + (int64_t)bz * a.strideC;
+                    *reinterpret_cast<float4*>(C + (int64_t)m * a.ldc + n) =
+                        make_float4(a.alpha * v[0] + b.x, a.alpha * v[1] + b.y, a.alpha * v[2] + b.z, a.alpha * v[3] + b.w);
+                } else {  // EPI_RESID
+                    float* C = reinterpret_cast<float*>(a.C) + (int64_t)bz * a.strideC;
+                    float4* p = reinterpret_cast<float4*>(C + (int64_t)m * a.ldc + n);
+                    float4 r = *p;
+                    *p = make_float4(r.x + v[0] + b.x, r.y + v[1] + b.y, r.z + v[2] + b.z, r.w + v[3] + b.w);
+                }
+            }
+        }
+    }
+}
+
+
+// ---- LDS-staged epilogue (LDS-DMA engine): the MFMA accumulator layout gives every lane 4 columns
+// of 16 different rows, so direct stores touch 32-64 B per row per instruction (measured: 40 % of
+// the FF1 kernel).  Instead each wave transposes one 16-row m-tile at a time through a private LDS
+// patch (row stride padded by 16 B) and writes it back as whole rows, 16 B per lane: full 128-B
+// lines.  Wave-private, so no workgroup barrier; LDS ops of one wave execute in order.
+template <int MT, int NT, int EPI>
+__device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[MT][NT], const GemmArgs& a, int mb, int nb, int bz, int lane,
+                                                  unsigned char* patch) {
+    const int fr = lane & 15, fq = lane >> 4;
+    constexpr bool F32OUT = (EPI == EPI_F32 || EPI == EPI_RESID);
+    constexpr int OC = (EPI == EPI_GEGLU) ? NT * 8 : NT * 16;            // output columns of this wave
+    constexpr int ROWB = OC * (F32OUT ? 4 : 2);                          // bytes per output row
+    constexpr int STRIDE = ROWB + 16;
+    constexpr int LPR = ROWB / 16;                                       // lanes per row (16 B each)
+    constexpr int RPI = 64 / LPR;                                        // rows per store instruction
+    static_assert(ROWB % 16 == 0 && 64 % LPR == 0 && 16 % RPI == 0 && 16 * STRIDE <= 8704, "epilogue tiling");
+    const int oc0 = (EPI == EPI_GEGLU) ? nb / 2 : nb;                     // first output column
+    const int ncols = (EPI == EPI_GEGLU) ? a.N / 2 : a.N;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        // ---- lane-owned values -> LDS patch [16 rows][OC]
+        if constexpr (EPI == EPI_GEGLU) {
+#pragma unroll
+            for (int p = 0; p < NT / 2; ++p) {
+                const int nx = nb + 32 * p + 4 * fq;
+                const float4 bx = *reinterpret_cast<const float4*>(a.bias + nx);
+                const float4 bg = *reinterpret_cast<const float4*>(a.bias + nx + 16);
+                const f32x4 x = acc[i][2 * p], g = acc[i][2 * p + 1];
+                *reinterpret_cast<bf16x4*>(patch + fr * STRIDE + (16 * p + 4 * fq) * 2) =
+                    pack4((x[0] + bx.x) * gelu_erf(g[0] + bg.x), (x[1] + bx.y) * gelu_erf(g[1] + bg.y),
+                          (x[2] + bx.z) * gelu_erf(g[2] + bg.z), (x[3] + bx.w) * gelu_erf(g[3] + bg.w));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = nb + j * 16 + 4 * fq;
+                float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.bias && n < a.N) b = *reinterpret_cast<const float4*>(a.bias + n);
+                const f32x4 v = acc[i][j];
+                const float o0 = a.alpha * v[0] + b.x, o1 = a.alpha * v[1] + b.y, o2 = a.alpha * v[2] + b.z, o3 = a.alpha * v[3] + b.w;
+                if constexpr (F32OUT) *reinterpret_cast<float4*>(patch + fr * STRIDE + (16 * j + 4 * fq) * 4) = make_float4(o0, o1, o2, o3);
+                else *reinterpret_cast<bf16x4*>(patch + fr * STRIDE + (16 * j + 4 * fq) * 2) = pack4(o0, o1, o2, o3);
+            }
+        }
+        // ---- whole rows back out: lane -> (row lane/LPR, 16-byte piece lane%LPR)
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0 += RPI) {
+            const int r = r0 + lane / LPR, pc = lane % LPR;
+            const int m = mb + i * 16 + r;
+            const uint4 v = *reinterpret_cast<const uint4*>(patch + r * STRIDE + pc * 16);
+            constexpr int EPP = F32OUT ? 4 : 8;                           // elements per 16-byte piece
+            const int c = oc0 + pc * EPP;
+            if (m < a.M && c < ncols) {
+                if constexpr (EPI == EPI_RESID) {
+                    float* C = reinterpret_cast<float*>(a.C) + (int64_t)bz * a.strideC + (int64_t)m * a.ldc + c;
+                    float4 x = *reinterpret_cast<float4*>(C);
+                    const float4 d = *reinterpret_cast<const float4*>(&v);
+                    x.x += d.x; x.y += d.y; x.z += d.z; x.w += d.w;
+                    *reinterpret_cast<float4*>(C) = x;
+                } else if constexpr (EPI == EPI_F32) {
+                    float* C = reinterpret_cast<float*>(a.C) + (int64_t)bz * a.strideC + (int64_t)m * a.ldc + c;
+                    *reinterpret_cast<uint4*>(C) = v;
+                } else {
+                    bf16* C = reinterpret_cast<bf16*>(a.C) + (int64_t)bz * a.strideC + (int64_t)m * a.ldc + c;
+                    if (c + 8 <= ncols) *reinterpret_cast<uint4*>(C) = v;
+                    else *reinterpret_cast<uint2*>(C) = make_uint2(v.x, v.y);   // N % 8 == 4 tail
+                }
+            }
+        }
+    }
+}
+
+// =================================================================================================
+// register-staged engine (4 waves, 2x2)
+// =================================================================================================
 template <int BM, int BN, int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     constexpr int BK = 64;
@@ -117,60 +253,134 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
         if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();
     }
-
-    // ---- epilogue: lane owns row m = ..+fr, 4 consecutive columns n = ..+4*fq+{0..3} -----
-    const int mb = m0 + wm * (BM / 2);
-    const int nb = n0 + wn * (BN / 2);
-    if constexpr (EPI == EPI_GEGLU) {
-        bf16* C = reinterpret_cast<bf16*>(a.C) + (int64_t)bz * a.strideC;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int m = mb + i * 16 + fr;
-            if (m >= a.M) continue;
-#pragma unroll
-            for (int p = 0; p < NT / 2; ++p) {
-                const int nx = nb + 32 * p + 4 * fq;           // packed row of the 'x' half
-                const int ng = nx + 16;                        // packed row of the gate half
-                float4 bx = *reinterpret_cast<const float4*>(a.bias + nx);
-                float4 bg = *reinterpret_cast<const float4*>(a.bias + ng);
-                f32x4 x = acc[i][2 * p], g = acc[i][2 * p + 1];
-                bf16x4 o = pack4((x[0] + bx.x) * gelu_erf(g[0] + bg.x), (x[1] + bx.y) * gelu_erf(g[1] + bg.y),
-                                 (x[2] + bx.z) * gelu_erf(g[2] + bg.z), (x[3] + bx.w) * gelu_erf(g[3] + bg.w));
-                const int c = nb / 2 + 16 * p + 4 * fq;
-                *reinterpret_cast<bf16x4*>(C + (int64_t)m * a.ldc + c) = o;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int m = mb + i * 16 + fr;
-            if (m >= a.M) continue;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int n = nb + j * 16 + 4 * fq;
-                if (n >= a.N) continue;                        // N is a multiple of 4
-                f32x4 v = acc[i][j];
-                float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (a.bias) b = *reinterpret_cast<const float4*>(a.bias + n);
-                if constexpr (EPI == EPI_BF16) {
-                    bf16* C = reinterpret_cast<bf16*>(a.C) + (int64_t)bz * a.strideC;
-                    *reinterpret_cast<bf16x4*>(C + (int64_t)m * a.ldc + n) =
-                        pack4(a.alpha * v[0] + b.x, a.alpha * v[1] + b.y, a.alpha * v[2] + b.z, a.alpha * v[3] + b.w);
-                } else if constexpr (EPI == EPI_F32) {
-                    float* C = reinterpret_cast<float*>(a.C) + (int64_t)bz * a.strideC;
-                    *reinterpret_cast<float4*>(C + (int64_t)m * a.ldc + n) =
-                        make_float4(a.alpha * v[0] + b.x, a.alpha * v[1] + b.y, a.alpha * v[2] + b.z, a.alpha * v[3] + b.w);
-                } else {  // EPI_RESID
-                    float* C = reinterpret_cast<float*>(a.C) + (int64_t)bz * a.strideC;
-                    float4* p = reinterpret_cast<float4*>(C + (int64_t)m * a.ldc + n);
-                    float4 r = *p;
-                    *p = make_float4(r.x + v[0] + b.x, r.y + v[1] + b.y, r.z + v[2] + b.z, r.w + v[3] + b.w);
-                }
-            }
-        }
-    }
+    gemm_epilogue<MT, NT, EPI>(acc, a, m0 + wm * (BM / 2), n0 + wn * (BN / 2), bz, fr, fq);
 }
 
+// =================================================================================================
+// LDS-DMA engine: WM x WN waves; NSTAGE LDS buffers
+// =================================================================================================
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+template <int BM, int BN, int WM, int WN, int NSTAGE, int EPI>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_glds_kernel(GemmArgs a) {
+    constexpr int BK = 64;
+    constexpr int WAVES = WM * WN;
+    constexpr int MT = BM / (16 * WM);       // m-tiles per wave
+    constexpr int NT = BN / (16 * WN);       // n-tiles per wave
+    constexpr int CA = BM / 8 / WAVES;       // 1-KiB DMA pieces (8 rows x 128 B) per wave for A
+    constexpr int CB = BN / 8 / WAVES;
+    constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [NSTAGE][A tile | B tile]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    // XCD-aware tile order (speed only): workgroups are dealt round-robin over the 8 XCDs, so the
+    // blocks with equal id%8 share an L2.  Give each of those 8 groups a CONTIGUOUS span of the
+    // n-fastest tile order: neighbouring tiles (same A row-panel, adjacent weight panels) then hit
+    // one L2 instead of eight.  Bijective for any grid size (guide 5: q/r form).
+    const int ntn = gridDim.x, nt = gridDim.x * gridDim.y;
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = lin & 7, q = nt >> 3, rr = nt & 7;
+    const int tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (lin >> 3);
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    const int bz = blockIdx.z;
+    const bf16* A = a.A + (int64_t)bz * a.strideA;
+    const bf16* B = a.B + (int64_t)bz * a.strideB;
+
+    // DMA source addresses.  Piece p of this wave covers tile rows 8*(wave + WAVES*p) .. +7; lane l
+    // lands in LDS at piece_base + 16*l = (row r = l>>3, physical chunk l&7), which must hold the
+    // LOGICAL chunk (l&7) ^ (r&7): the XOR goes on the source address, the destination stays linear.
+    const int lr = lane >> 3;
+    const int lc = (lane & 7) ^ lr;
+    const bf16* gA[CA];
+    const bf16* gB[CB];
+#pragma unroll
+    for (int p = 0; p < CA; ++p) {
+        int r = m0 + 8 * (wave + WAVES * p) + lr;
+        r = r < a.M ? r : a.M - 1;
+        gA[p] = A + (int64_t)r * a.lda + lc * 8;
+    }
+#pragma unroll
+    for (int p = 0; p < CB; ++p) {
+        int r = n0 + 8 * (wave + WAVES * p) + lr;
+        r = r < a.N ? r : a.N - 1;
+        gB[p] = B + (int64_t)r * a.ldb + lc * 8;
+    }
+    auto stage = [&](int kt, int buf) {
+        unsigned char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int p = 0; p < CA; ++p)
+            __builtin_amdgcn_global_load_lds((glb_void*)(gA[p] + kt * BK), (lds_void*)(base + (wave + WAVES * p) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int p = 0; p < CB; ++p)
+            __builtin_amdgcn_global_load_lds((glb_void*)(gB[p] + kt * BK), (lds_void*)(base + BM * 128 + (wave + WAVES * p) * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = a.K / BK;
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < nk) stage(s, s);
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt must have landed: allow the NSTAGE-2 younger tiles to stay in flight
+        if (kt + NSTAGE - 2 < nk) {
+            if constexpr (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * (CA + CB)) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // everyone's pieces of tile kt are in LDS; buffer (kt-1)%NSTAGE is free
+        asm volatile("" ::: "memory");
+        if (kt + NSTAGE - 1 < nk && !(a.ablate & 1)) stage(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);
+        const bf16x8* sA = reinterpret_cast<const bf16x8*>(smem + (kt % NSTAGE) * STAGE_BYTES);
+        const bf16x8* sB = sA + BM * 8;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[MT], fb[NT];
+            const int chunk = kk * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int r = wm * (BM / WM) + i * 16 + fr;
+                fa[i] = sA[r * 8 + (chunk ^ (r & 7))];
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int r = wn * (BN / WN) + j * 16 + fr;
+                fb[j] = sB[r * 8 + (chunk ^ (r & 7))];
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (a.ablate & 2) {                       // diagnostics: keep the accumulators live, store (almost) nothing
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (s == 1234.5678f) reinterpret_cast<float*>(a.C)[0] = s;
+        return;
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();             // every wave is done reading the staging buffers: reuse them as patches
+    asm volatile("" ::: "memory");
+    gemm_epilogue_lds<MT, NT, EPI>(acc, a, m0 + wm * (BM / WM), n0 + wn * (BN / WN), bz, lane, smem + wave * 8704);
+}
+
+// -------------------------------------------------------------------------------------------------
 template <int BM, int BN>
 static int launch_tile(const GemmArgs& a, int epi, hipStream_t st) {
     dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), a.batch);
@@ -183,6 +393,33 @@ static int launch_tile(const GemmArgs& a, int epi, hipStream_t st) {
     }
     RALD_HIP(hipGetLastError());
     return 0;
+}
+
+template <int BM, int BN, int WM, int WN, int NSTAGE, int EPI>
+static int launch_glds_epi(const GemmArgs& a, hipStream_t st) {
+    constexpr int WAVES = WM * WN;
+    constexpr int smem = NSTAGE * (BM + BN) * 64 * 2;
+    static_assert(smem >= WAVES * 8704, "epilogue patches must fit in the staging buffers");
+    static bool attr_set = false;
+    auto kern = gemm_nt_glds_kernel<BM, BN, WM, WN, NSTAGE, EPI>;
+    if (!attr_set && smem > 64 * 1024) {
+        RALD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), a.batch);
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), smem, st, a);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+static int launch_glds(const GemmArgs& a, int epi, hipStream_t st) {
+    switch (epi) {
+        case EPI_BF16:  return launch_glds_epi<BM, BN, WM, WN, NSTAGE, EPI_BF16>(a, st);
+        case EPI_F32:   return launch_glds_epi<BM, BN, WM, WN, NSTAGE, EPI_F32>(a, st);
+        case EPI_RESID: return launch_glds_epi<BM, BN, WM, WN, NSTAGE, EPI_RESID>(a, st);
+        case EPI_GEGLU: return launch_glds_epi<BM, BN, WM, WN, NSTAGE, EPI_GEGLU>(a, st);
+        default: set_error("gemm: bad epilogue"); return 1;
+    }
 }
 
 // Host-side shape contract is checked here, before any launch (an out-of-bounds MFMA tile
@@ -201,10 +438,31 @@ int gemm_nt(const GemmArgs& a, int epi, hipStream_t st) {
     } else {
         RALD_CHECK(a.ldc >= a.N, "gemm: ldc < N");
     }
-    // 128x128 tiles when they fill the chip; 64x64 tiles for the small-M (batch-1) regime.
+    // engine selection.  Default (-1): LDS-DMA 256x256 tiles (8 waves) when they give every CU at
+    // least one tile, LDS-DMA 128x128 (4 waves, 2 workgroups/CU) otherwise, register-staged 64x64 for
+    // the small-M (batch-1) regime.  RALD_GEMM_IMPL forces a variant for A/B microbenchmarks:
+    // 0 register-staged 128x128, 1 LDS-DMA 128x128 2 stages, 2 ... 3 stages, 3 LDS-DMA 256x128 2 stages,
+    // 4 256x128 3 stages, 5 256x256 2 stages.
+    int impl = -1;
+    if (const char* e = getenv("RALD_GEMM_IMPL")) impl = atoi(e);
     const int64_t wg128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) * a.batch;
-    if (wg128 >= 192) return launch_tile<128, 128>(a, epi, st);
-    return launch_tile<64, 64>(a, epi, st);
+    if (wg128 < 192) return launch_tile<64, 64>(a, epi, st);      // small-M (batch-1) regime
+    if (impl < 0) {
+        const int64_t wg256 = (int64_t)(a.M / 256) * (a.N / 256) * a.batch;
+        if (a.M % 256 == 0 && a.N % 256 == 0 && wg256 >= 256) return launch_glds<256, 256, 4, 2, 2>(a, epi, st);
+        return launch_glds<128, 128, 2, 2, 2>(a, epi, st);
+    }
+    switch (impl) {
+        case 0: return launch_tile<128, 128>(a, epi, st);
+        case 2: return launch_glds<128, 128, 2, 2, 3>(a, epi, st);
+        case 3: if (a.M % 256 == 0 && wg128 >= 512) return launch_glds<256, 128, 4, 2, 2>(a, epi, st);
+                return launch_glds<128, 128, 2, 2, 2>(a, epi, st);
+        case 4: if (a.M % 256 == 0 && wg128 >= 512) return launch_glds<256, 128, 4, 2, 3>(a, epi, st);
+                return launch_glds<128, 128, 2, 2, 2>(a, epi, st);
+        case 5: if (a.M % 256 == 0 && a.N % 256 == 0 && wg128 >= 1024) return launch_glds<256, 256, 4, 2, 2>(a, epi, st);
+                return launch_glds<128, 128, 2, 2, 2>(a, epi, st);
+        default: return launch_glds<128, 128, 2, 2, 2>(a, epi, st);
+    }
 }
 
 }  // namespace rald

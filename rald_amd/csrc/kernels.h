@@ -13,13 +13,14 @@ struct GemmArgs {
     const float* bias;                             // [N] or nullptr
     int M, N, K, batch;
     float alpha;
+    int ablate;                                    // diagnostics only (RALD_GEMM_ABLATE): 1 = no DMA in the loop, 2 = no epilogue
 };
 int gemm_nt(const GemmArgs& a, int epi, hipStream_t st);
 inline GemmArgs gemm_args(const bf16* A, int64_t lda, const bf16* B, int64_t ldb, void* C, int64_t ldc,
                           const float* bias, int M, int N, int K) {
     GemmArgs g;
     g.A = A; g.lda = lda; g.strideA = 0; g.B = B; g.ldb = ldb; g.strideB = 0;
-    g.C = C; g.ldc = ldc; g.strideC = 0; g.bias = bias; g.M = M; g.N = N; g.K = K; g.batch = 1; g.alpha = 1.f;
+    g.C = C; g.ldc = ldc; g.strideC = 0; g.bias = bias; g.M = M; g.N = N; g.K = K; g.batch = 1; g.alpha = 1.f; g.ablate = 0;
     return g;
 }
 

@@ -1,0 +1,18 @@
+import os, sys, torch
+sys.path.insert(0, ".")
+from rald_amd import _handles as H
+def run(M,N,K,epi,impl,abl,reps=20):
+    os.environ["RALD_GEMM_IMPL"]=str(impl); os.environ["RALD_GEMM_ABLATE"]=str(abl)
+    A=torch.randn(M,K,device="cuda").bfloat16(); W=(torch.randn(N,K,device="cuda")/K**0.5).bfloat16(); b=torch.randn(N,device="cuda")
+    x=torch.zeros(M,N,device="cuda") if epi==2 else None
+    f=lambda: H.op_gemm_nt(A,W,bias=b,epilogue=epi,C_inout=x)
+    for _ in range(3): f()
+    torch.cuda.synchronize(); s,e=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps): f()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e)/reps*1e3
+M=16384
+for name,N,K,epi in [("ff1",4096,512,3),("ff1-bf16epi",4096,512,0),("ff2",512,2048,2),("qk",1024,512,0)]:
+    for impl in (1,5):
+        print(name, f"impl{impl}", " ".join(f"abl{a}:{run(M,N,K,epi,impl,a):7.1f}us" for a in (0,1,2,3)), flush=True)
