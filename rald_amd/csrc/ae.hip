@@ -31,7 +31,7 @@ int Ae::create() {
     I = c.heads * c.dim_head;
     RALD_CHECK(c.dim_head == 64 && I == 512, "ae: heads*dim_head must be 8x64 (create_autoencoder hard-codes it, models_ae.py:447-458)");
     RALD_CHECK(d == 256 || d == 512, "ae: dim must be 256 or 512");
-    RALD_CHECK(c.num_latents > 0 && c.num_latents % 32 == 0, "ae: num_latents must be a multiple of 32");
+    RALD_CHECK(c.num_latents > 0 && c.num_latents % 64 == 0, "ae: num_latents must be a multiple of 64");
     RALD_CHECK(c.latent_dim >= 1 && c.latent_dim <= 64 && (2 * c.latent_dim) % 4 == 0, "ae: latent_dim must be in [2,64] and even");
     RALD_CHECK(c.depth >= 1 && c.depth <= 256, "ae: bad depth");
     RALD_CHECK(c.num_inputs >= 32, "ae: num_inputs too small");

@@ -1,33 +1,64 @@
 // Flash-style multi-head attention for head dim 64 on v_mfma_f32_32x32x16_bf16
 // (CrossAttention, models_radar_generation.py:66-75; Attention, models_ae.py:91-104).
 //
-// One wave owns 32 queries of one (batch, head) and streams the keys in tiles of 32 with an
-// online softmax; nothing of the [nq x nk] score matrix ever reaches memory (the reference
-// materialises it in fp32).  CDNA4-specific structure:
-//   * S^T = K.Q^T (keys on the accumulator ROWS, the query on the LANE): every lane holds 16 of
-//     its query's 32 scores, its partner lane (lane^32) the other 16, so the row max / row sum
-//     are 15 in-register ops + ONE cross-half exchange, and the rescale factor is lane-local.
-//   * The S^T accumulator is then directly the B operand of O^T = V^T.P^T (sum over the
-//     accumulator's row index) - no LDS round trip, no lane movement.  The k order inside a
-//     16-key step is permuted (element j of lane half h is key 16s + 8(j>>2) + 4h + (j&3)),
-//     so the V^T fragment is gathered as two 8-byte pieces in that same order.
-//   * V arrives pre-transposed (Vt[b][h*64+d][key], keys contiguous): the producing GEMM is
-//     simply issued with the operand roles swapped, so no transpose pass exists anywhere.
+// One workgroup = 4 waves = 128 queries of one (batch, head); each wave owns 32 queries and the
+// whole workgroup streams the keys in tiles of 64 with an online softmax.  Nothing of the
+// [nq x nk] score matrix reaches memory (the reference materialises it in fp32).  CDNA4 structure:
+//   * K and V^T tiles (8 KB each) are written straight into LDS by LDS-DMA (global_load_lds_dwordx4),
+//     double-buffered, one barrier per tile; the 16-byte chunks of the 128-byte LDS rows are
+//     XOR-swizzled via the DMA SOURCE address so the fragment reads are bank-conflict free.
+//   * S^T = K.Q^T (keys on the accumulator ROWS, the query on the LANE): every lane holds 16 of its
+//     query's 32 scores per sub-tile, its partner lane (lane^32) the other 16, so the row max / row
+//     sum are in-register ops + ONE cross-half exchange, and the rescale factor is lane-local.
+//   * The S^T accumulator is directly the B operand of O^T = V^T.P^T (sum over the accumulator's row
+//     index): no LDS round trip for P.  The k order inside a 16-key step is permuted (element j of
+//     lane half h is key 16s + 8(j>>2) + 4h + (j&3)), so the V^T fragment is two 8-byte LDS reads in
+//     that same order.
+//   * V arrives pre-transposed (Vt[b][h*64+d][key], keys contiguous): the producing GEMM is issued
+//     with the operand roles swapped, so no transpose pass exists anywhere.
+//   * softmax scale and log2(e) ride in the exp2 argument's FMA; masking runs only on a ragged last
+//     tile; the O rescale is skipped (wave-uniformly) when no lane's running max moved.
+//   * O leaves through a wave-private LDS transpose as whole 128-byte rows.
 #include "common.h"
 #include "kernels.h"
 
 namespace rald {
 
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
+    constexpr int TILE_BYTES = 64 * 128;                       // 64 rows x 128 B (K: keys x d, Vt: d x keys)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE_BYTES];   // [buf][K | Vt]
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hf = lane >> 5;
-    const int q0 = (blockIdx.x * 4 + wave) * 32;
-    if (q0 >= a.nq) return;                                  // no barriers below: early exit is safe
     const int h = blockIdx.y, b = blockIdx.z;
+    int q0 = (blockIdx.x * 4 + wave) * 32;
+    const bool active = q0 < a.nq;                             // a ragged last workgroup still helps staging
+    if (!active) q0 = a.nq - 32;
     const bf16* Q = a.Q + (int64_t)b * a.strideQ + (int64_t)(q0 + r) * a.ldq + h * 64 + 8 * hf;
-    const bf16* K = a.K + (int64_t)b * a.strideK + (int64_t)r * a.ldk + h * 64 + 8 * hf;
-    const bf16* Vt = a.Vt + (int64_t)b * a.strideVt + (int64_t)(h * 64 + r) * a.ldvt + 4 * hf;
+
+    // DMA sources: piece p of this wave = tile rows 8*(wave + 4p) .. +7; lane -> (row l>>3, phys chunk l&7)
+    const int lr = lane >> 3, lc = (lane & 7) ^ lr;
+    const bf16* gK[2];
+    const bf16* gV[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int row = 8 * (wave + 4 * p) + lr;
+        gK[p] = a.K + (int64_t)b * a.strideK + (int64_t)row * a.ldk + h * 64 + lc * 8;
+        gV[p] = a.Vt + (int64_t)b * a.strideVt + (int64_t)(h * 64 + row) * a.ldvt + lc * 8;
+    }
+    auto stage = [&](int j0, int buf) {
+        unsigned char* base = smem + buf * 2 * TILE_BYTES;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            __builtin_amdgcn_global_load_lds((glb_void*)(gK[p] + (int64_t)j0 * a.ldk), (lds_void*)(base + (wave + 4 * p) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(gV[p] + j0), (lds_void*)(base + TILE_BYTES + (wave + 4 * p) * 1024), 16, 0, 0);
+        }
+    };
 
     bf16x8 qf[4];
 #pragma unroll
@@ -36,80 +67,121 @@ __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
     f32x16 o0, o1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
-    float m = -1e30f, l = 0.f;
-    const float sc = a.scale * 1.4426950408889634f;          // exp(x) = exp2(x*log2e)
+    float m = -1e30f, l = 0.f;                                 // m: running max of the RAW scores
+    const float c = a.scale * 1.4426950408889634f;             // exp(scale*s) = exp2(c*s)
 
-    for (int j0 = 0; j0 < a.nk; j0 += 32) {
-        bf16x8 kf[4];
+    const int ntiles = (a.nk + 63) / 64;
+    stage(0, 0);
+    for (int t = 0; t < ntiles; ++t) {
+        const int j0 = t * 64;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my pieces of tile t have landed
+        __builtin_amdgcn_s_barrier();                          // ... and everyone's; buffer (t+1)&1 is free
+        asm volatile("" ::: "memory");
+        if (t + 1 < ntiles) stage(j0 + 64, (t + 1) & 1);
+        const unsigned char* sK = smem + (t & 1) * 2 * TILE_BYTES;
+        const unsigned char* sV = sK + TILE_BYTES;
+
+        // ---- S^T = K.Q^T for the two 32-key sub-tiles
+        f32x16 st[2];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const bf16x8*>(K + (int64_t)j0 * a.ldk + 16 * s);
-        // V^T fragments for this tile: [d-tile][k-step], element j <-> key j0 + 16s + 8(j>>2) + 4hf + (j&3)
-        bf16x8 vf[2][2];
+        for (int u = 0; u < 2; ++u) {
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+            for (int i = 0; i < 16; ++i) st[u][i] = 0.f;
+            const int krow = 32 * u + r;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16* p = Vt + (int64_t)(32 * dt) * a.ldvt + j0 + 16 * s;
-                bf16x4 lo = *reinterpret_cast<const bf16x4*>(p);
-                bf16x4 hi = *reinterpret_cast<const bf16x4*>(p + 8);
-                vf[dt][s] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + krow * 128 + (((2 * s + hf) ^ (krow & 7)) << 4));
+                st[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[u], 0, 0, 0);
             }
-        f32x16 st;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) st[i] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[s], st, 0, 0, 0);
-
-        // st[i] = score(key j0 + (i&3) + 8*(i>>2) + 4*hf, query q0 + r)
-        float mx = -1e30f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int key = j0 + (i & 3) + 8 * (i >> 2) + 4 * hf;
-            st[i] = key < a.nk ? st[i] * sc : -1e30f;
-            mx = fmaxf(mx, st[i]);
         }
+        // st[u][i] = raw score(key j0 + 32u + (i&3) + 8*(i>>2) + 4*hf, query q0 + r)
+        if (j0 + 64 > a.nk) {                                  // ragged last tile only (wave-uniform)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (j0 + 32 * u + (i & 3) + 8 * (i >> 2) + 4 * hf >= a.nk) st[u][i] = -1e30f;
+        }
+        float mx = st[0][0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, st[0][i]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[1][i]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mn = fmaxf(m, mx);
-        const float alpha = exp2f(m - mn);
-        m = mn;
+        if (__any(mx > m)) {                                   // somebody's max moved: rescale what is at the old max
+            const float mn = fmaxf(m, mx);
+            const float alpha = fast_exp2((m - mn) * c);
+            m = mn;
+            l *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+        }
+        const float mc = -m * c;
         float ps = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            st[i] = exp2f(st[i] - mn);
-            ps += st[i];
-        }
-        l = l * alpha + ps;                                   // per-half partial; halves summed at the end
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
-        bf16x8 pf[2];
+            for (int i = 0; i < 16; ++i) {
+                st[u][i] = fast_exp2(fmaf(st[u][i], c, mc));
+                ps += st[u][i];
+            }
+        l += ps;                                               // per-half partial; halves summed at the end
+
+        // ---- O^T += V^T.P^T ; element j of the P fragment <-> key 32u + 16s + 8(j>>2) + 4hf + (j&3)
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pf[s][j] = (bf16)st[8 * s + j];
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 pf;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][s], pf[s], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][s], pf[s], o1, 0, 0, 0);
-        }
+                for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[u][8 * s + j];
+                const int ch = 4 * u + 2 * s;                  // 8-key chunk holding keys 32u+16s .. +7
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int vrow = 32 * dt + r;
+                    const unsigned char* vr = sV + vrow * 128 + 8 * hf;
+                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vr + ((ch ^ (vrow & 7)) << 4));
+                    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vr + (((ch + 1) ^ (vrow & 7)) << 4));
+                    const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o0, 0, 0, 0);
+                    else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o1, 0, 0, 0);
+                }
+            }
     }
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
-    // o{dt}[i] = O^T[d = 32dt + (i&3) + 8(i>>2) + 4hf][query q0+r]: 4 consecutive d per register group
-    bf16* O = a.O + (int64_t)b * a.strideO + (int64_t)(q0 + r) * a.ldo + h * 64 + 4 * hf;
+
+    // ---- O out: o{dt}[i] = O^T[d = 32dt + (i&3) + 8(i>>2) + 4hf][query q0+r].  Transpose through a
+    // wave-private LDS patch [32 queries][128 B + 16] and store whole 128-byte rows.
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();                              // all waves are done with the K/V buffers
+    asm volatile("" ::: "memory");
+    unsigned char* patch = smem + wave * (32 * 144);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        *reinterpret_cast<bf16x4*>(O + 8 * g) = pack4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
-        *reinterpret_cast<bf16x4*>(O + 32 + 8 * g) = pack4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        *reinterpret_cast<bf16x4*>(patch + r * 144 + (8 * g + 4 * hf) * 2) =
+            pack4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+        *reinterpret_cast<bf16x4*>(patch + r * 144 + (32 + 8 * g + 4 * hf) * 2) =
+            pack4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+    }
+    if (active) {
+        bf16* O = a.O + (int64_t)b * a.strideO + (int64_t)q0 * a.ldo + h * 64;
+#pragma unroll
+        for (int r0 = 0; r0 < 32; r0 += 8) {
+            const int row = r0 + (lane >> 3), pc = lane & 7;
+            const uint4 v = *reinterpret_cast<const uint4*>(patch + row * 144 + pc * 16);
+            *reinterpret_cast<uint4*>(O + (int64_t)row * a.ldo + pc * 8) = v;
+        }
     }
 }
 
 int attention_d64(const AttnArgs& a, hipStream_t st) {
     RALD_CHECK(a.nq > 0 && a.nk > 0 && a.heads > 0 && a.batch > 0, "attention: empty problem");
     RALD_CHECK(a.nq % 32 == 0, "attention: nq must be a multiple of 32");
-    RALD_CHECK(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldvt % 4 == 0 && a.ldo % 4 == 0, "attention: leading dimensions must keep 16/8-byte alignment");
-    RALD_CHECK(a.k_rows >= round_up(a.nk, 32), "attention: K must have rows allocated up to a multiple of 32 keys");
-    RALD_CHECK(a.ldvt >= round_up(a.nk, 32), "attention: Vt rows must be padded (zero-filled) to a multiple of 32 keys");
-    RALD_CHECK(((uintptr_t)a.Q % 16 == 0) && ((uintptr_t)a.K % 16 == 0) && ((uintptr_t)a.Vt % 8 == 0) && ((uintptr_t)a.O % 8 == 0), "attention: pointer alignment");
+    RALD_CHECK(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldvt % 8 == 0 && a.ldo % 8 == 0, "attention: leading dimensions must be multiples of 8 elements (16-byte rows)");
+    RALD_CHECK(a.k_rows >= round_up(a.nk, 64), "attention: K must have rows allocated up to a multiple of 64 keys (the tail tile is staged whole)");
+    RALD_CHECK(a.ldvt >= round_up(a.nk, 64), "attention: Vt rows must be padded (finite values) to a multiple of 64 keys");
+    RALD_CHECK(((uintptr_t)a.Q % 16 == 0) && ((uintptr_t)a.K % 16 == 0) && ((uintptr_t)a.Vt % 16 == 0) && ((uintptr_t)a.O % 16 == 0), "attention: pointers must be 16-byte aligned");
     dim3 grid(cdiv(a.nq, 128), a.heads, a.batch);
     hipLaunchKernelGGL(attention_d64_kernel, grid, dim3(256), 0, st, a);
     RALD_HIP(hipGetLastError());

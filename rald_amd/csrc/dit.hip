@@ -95,11 +95,11 @@ int Dit::create() {
     D = c.n_heads * c.d_head;
     RALD_CHECK(c.d_head == 64, "dit: only d_head = 64 is implemented");
     RALD_CHECK(D == 512, "dit: inner dim (n_heads*d_head) must be 512");
-    RALD_CHECK(c.n_latents > 0 && c.n_latents % 32 == 0, "dit: n_latents must be a positive multiple of 32");
+    RALD_CHECK(c.n_latents > 0 && c.n_latents % 64 == 0, "dit: n_latents must be a positive multiple of 64");
     RALD_CHECK(c.channels >= 1 && c.channels <= 64, "dit: channels must be in [1,64]");
     RALD_CHECK(c.depth >= 1 && c.depth <= 256, "dit: bad depth");
     RALD_CHECK(c.context_dim % 64 == 0 && c.context_dim > 0, "dit: context_dim must be a multiple of 64");
-    RALD_CHECK(c.n_cond_tokens > 0 && c.n_cond_tokens % 32 == 0, "dit: n_cond_tokens must be a multiple of 32");
+    RALD_CHECK(c.n_cond_tokens > 0 && c.n_cond_tokens % 64 == 0, "dit: n_cond_tokens must be a multiple of 64");
     RALD_CHECK(c.t_channels % 4 == 0, "dit: t_channels must be a multiple of 4");
     const int L = c.depth;
     layers.resize(L);

@@ -100,7 +100,7 @@ def _attn_ref(q, k, v, heads, scale):
 @pytest.mark.parametrize("B,nq,nk,heads", [(2, 512, 512, 8), (1, 128, 64, 8), (3, 512, 64, 8), (1, 512, 1000, 8), (2, 96, 10000, 2)])
 def test_attention_d64(H, B, nq, nk, heads):
     HD = heads * 64
-    nkp = (nk + 31) // 32 * 32
+    nkp = (nk + 63) // 64 * 64
     g = torch.Generator("cpu").manual_seed(3)
     q = torch.randn(B, nq, HD, generator=g).cuda().bfloat16()
     k = torch.zeros(B, nkp, HD).cuda().bfloat16()
@@ -126,6 +126,8 @@ def test_attention_exact_one_hot(H):
         q[0, i, i] = 16.0
         k[0, sel[i], i] = 16.0                         # query i matches key sel[i]: score 256 vs -256
     v = _ints((B, nk, 64), -8, 8, 5)
-    vt = v.transpose(1, 2).contiguous()
-    out = H.op_attention(q.cuda().bfloat16(), k.cuda().bfloat16(), vt.cuda().bfloat16(), nk, heads, 1.0)
+    nkp = 128                                          # K rows / Vt columns padded to a multiple of 64
+    kp = torch.zeros(B, nkp, 64); kp[:, :nk] = k
+    vt = torch.zeros(B, 64, nkp); vt[:, :, :nk] = v.transpose(1, 2)
+    out = H.op_attention(q.cuda().bfloat16(), kp.cuda().bfloat16(), vt.cuda().bfloat16(), nk, heads, 1.0)
     assert torch.equal(out.float().cpu()[0], v[0, sel])
