@@ -3,6 +3,7 @@ current torch stream -> hipStream_t) around librald_hip.so.  No arithmetic happe
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Iterable, Optional, Tuple
 
 import torch
@@ -28,6 +29,52 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(torch.float32).contiguous()
 
 
+# Launch-bound regime (small batches): one sampler run is ~10 000 kernel launches of a few
+# microseconds each, so the whole call is captured once into a hipGraph (torch.cuda.CUDAGraph on
+# the current stream - the library only enqueues kernels on the stream it is given) and replayed.
+# RALD_GRAPH=0 disables it; batches above GRAPH_MAX_BATCH run eagerly (they are GPU-bound).
+GRAPH_MAX_BATCH = int(os.environ.get("RALD_GRAPH_MAX_BATCH", "16"))
+
+
+def _graphs_enabled() -> bool:
+    return os.environ.get("RALD_GRAPH", "1") != "0"
+
+
+class _GraphCache:
+    """key -> (CUDAGraph, static inputs, static outputs).  Everything a captured graph points at
+    (handle workspace, sigma table, static tensors) must stay put; owners call clear() when any of
+    it may move."""
+
+    def __init__(self):
+        self.entries: Dict[tuple, tuple] = {}
+
+    def clear(self):
+        self.entries.clear()
+
+    def run(self, key, inputs, make_outputs, fn):
+        ent = self.entries.get(key)
+        if ent is None:
+            static_in = [t.clone() for t in inputs]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                   # warm-up outside capture: lazy allocations,
+                outs = make_outputs()                       # function attributes, sigma tables
+                fn(static_in, outs)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                outs = make_outputs()
+                fn(static_in, outs)
+            ent = (g, static_in, outs)
+            self.entries[key] = ent
+        g, static_in, outs = ent
+        for dst, src in zip(static_in, inputs):
+            dst.copy_(src, non_blocking=True)
+        g.replay()
+        return [o.clone() for o in outs]
+
+
 class DitHandle:
     """rald_dit* + its condition cache.  One handle per module per device."""
 
@@ -35,8 +82,9 @@ class DitHandle:
         self.cfg = cfg
         self._h = C.c_void_p()
         check(lib().rald_dit_create(C.byref(cfg), C.byref(self._h)))
-        self._cache: Optional[torch.Tensor] = None
-        self._cache_batch = 0
+        self._graphs = _GraphCache()
+        self._reserved = 0
+        self._sched = None
 
     def __del__(self):
         try:
@@ -101,13 +149,34 @@ class DitHandle:
         check(lib().rald_dit_profile_end(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
-    def sample(self, latents: torch.Tensor, cache: torch.Tensor, num_steps: int = 18, sigma_min: float = 0.002,
-               sigma_max: float = 80.0, rho: float = 7.0) -> torch.Tensor:
-        _need_cuda(latents, "latents")
-        latents = _f32c(latents)
-        out = torch.empty_like(latents)
+    def reserve(self, batch: int) -> None:
+        if batch > self._reserved:
+            self._graphs.clear()                       # workspace may move: captured graphs are stale
+            check(lib().rald_dit_reserve(self._h, batch))
+            self._reserved = batch
+
+    def _sample_eager(self, latents, cache, out, num_steps, sigma_min, sigma_max, rho):
         check(lib().rald_dit_sample(self._h, C.c_void_p(_ptr(latents)), latents.shape[0], C.c_void_p(_ptr(cache)), num_steps,
                                     sigma_min, sigma_max, rho, C.c_void_p(_ptr(out)), C.c_void_p(_stream())))
+
+    def sample(self, latents: torch.Tensor, cache: torch.Tensor, num_steps: int = 18, sigma_min: float = 0.002,
+               sigma_max: float = 80.0, rho: float = 7.0, use_graph: Optional[bool] = None) -> torch.Tensor:
+        _need_cuda(latents, "latents")
+        latents = _f32c(latents)
+        B = latents.shape[0]
+        self.reserve(B)
+        sched = (num_steps, float(sigma_min), float(sigma_max), float(rho))
+        if sched != self._sched:                       # the sampler's sigma table is rebuilt for a new schedule
+            self._graphs.clear()
+            self._sched = sched
+        if use_graph is None:
+            use_graph = _graphs_enabled() and B <= GRAPH_MAX_BATCH
+        if not use_graph:
+            out = torch.empty_like(latents)
+            self._sample_eager(latents, cache, out, *sched)
+            return out
+        (out,) = self._graphs.run(("sample", B) + sched, [latents, cache], lambda: [torch.empty_like(latents)],
+                                  lambda ins, outs: self._sample_eager(ins[0], ins[1], outs[0], *sched))
         return out
 
 
@@ -162,6 +231,8 @@ class AeHandle:
         self.cfg = cfg
         self._h = C.c_void_p()
         check(lib().rald_ae_create(C.byref(cfg), C.byref(self._h)))
+        self._graphs = _GraphCache()
+        self._dec_batch = 0
 
     def __del__(self):
         try:
@@ -193,11 +264,25 @@ class AeHandle:
                                    C.c_void_p(_ptr(z)), C.c_void_p(_ptr(kl)), C.c_void_p(_stream())))
         return (kl, z, mean, logvar) if want_moments else (kl, z)
 
-    def decode_latents(self, z: torch.Tensor) -> torch.Tensor:
+    def _decode_latents_eager(self, z, ctx):
+        check(lib().rald_ae_decode_latents(self._h, C.c_void_p(_ptr(z)), z.shape[0], C.c_void_p(_ptr(ctx)), C.c_void_p(_stream())))
+
+    def decode_latents(self, z: torch.Tensor, use_graph: Optional[bool] = None) -> torch.Tensor:
         _need_cuda(z, "latents")
         z = _f32c(z)
-        ctx = torch.empty(lib().rald_ae_ctx_bytes(self._h, z.shape[0]), dtype=torch.uint8, device=z.device)
-        check(lib().rald_ae_decode_latents(self._h, C.c_void_p(_ptr(z)), z.shape[0], C.c_void_p(_ptr(ctx)), C.c_void_p(_stream())))
+        B = z.shape[0]
+        nbytes = lib().rald_ae_ctx_bytes(self._h, B)
+        if use_graph is None:
+            use_graph = _graphs_enabled() and B <= GRAPH_MAX_BATCH
+        if B > self._dec_batch:                        # the latent-stack workspace grows: captured graphs are stale
+            self._graphs.clear()
+            self._dec_batch = B
+        if not use_graph:
+            ctx = torch.empty(nbytes, dtype=torch.uint8, device=z.device)
+            self._decode_latents_eager(z, ctx)
+            return ctx
+        (ctx,) = self._graphs.run(("dec", B), [z], lambda: [torch.empty(nbytes, dtype=torch.uint8, device=z.device)],
+                                  lambda ins, outs: self._decode_latents_eager(ins[0], outs[0]))
         return ctx
 
     def decode_queries(self, ctx: torch.Tensor, queries: torch.Tensor) -> torch.Tensor:

@@ -65,12 +65,17 @@ struct Dit {
     RadarEncoder radar;
     std::set<std::string> expected, loaded;
     bool finalized = false;
-    // noise-level table
-    std::string sigma_key;
-    std::vector<float> h_sigma;
-    int n_sigma = 0, sig_cap = 0;
-    float *d_sigma = nullptr, *d_coef = nullptr, *d_cnoise = nullptr, *d_pe = nullptr, *d_temb0 = nullptr, *d_temb = nullptr,
-          *d_mod = nullptr;
+    // noise-level tables: slot 0 = ad-hoc (rald_dit_set_sigmas / forward), slot 1 = the sampler's schedule.
+    // Separate slots so that a captured hipGraph of the sampler keeps pointing at valid modulations
+    // even if forward() is called with other sigmas in between.
+    struct SigmaTable {
+        std::string key;
+        std::vector<float> host;
+        int n = 0, cap = 0;
+        float *sigma = nullptr, *coef = nullptr, *cnoise = nullptr, *pe = nullptr, *temb0 = nullptr, *temb = nullptr, *mod = nullptr;
+    };
+    SigmaTable tables[2];
+    int build_table(SigmaTable& t, const float* sig, int n, hipStream_t st);
     int64_t mod_row() const { return (int64_t)cfg.depth * 3 * 2 * D; }
     // activation workspace
     int ws_batch = 0;
@@ -93,7 +98,7 @@ struct Dit {
     int64_t cond_cache_bytes(int B) const;
     int encode_cond_tokens(const float* tokens, int B, void* cache, hipStream_t st);
     int encode_cond(const float* cube, int B, float* out_tokens, void* cache, hipStream_t st);
-    int denoise(const float* x, int B, int sigma_row, int per_sample, const void* cache, float* out, int raw_F, hipStream_t st);
+    int denoise(const float* x, int B, int sigma_row, int per_sample, const void* cache, float* out, int raw_F, hipStream_t st, int slot = 0);
     int sample(const float* latents, int B, const void* cache, int num_steps, float smin, float smax, float rho, float* out,
                hipStream_t st);
 };

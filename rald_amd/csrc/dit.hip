@@ -217,7 +217,8 @@ int Dit::load_weight(const std::string& name, const float* data, int64_t nelem) 
     else RALD_CHECK(false, "dit: unknown key '" + name + "'");
     if (rc) return rc;
     loaded.insert(name);
-    sigma_key.clear();   // any cached table depends on the weights
+    tables[0].key.clear();   // any cached table depends on the weights
+    tables[1].key.clear();
     return 0;
 }
 
@@ -268,39 +269,41 @@ __global__ void edm_coef_kernel(const float* __restrict__ sigma, float* __restri
     c_noise[i] = cn;
 }
 
-int Dit::set_sigmas(const float* sig, int n, hipStream_t st) {
+int Dit::build_table(SigmaTable& t, const float* sig, int n, hipStream_t st) {
     RALD_CHECK(finalized, "dit: weights not finalized");
     RALD_CHECK(n >= 1 && n <= 4096, "dit: sigma table must have 1..4096 rows");
     std::string key((const char*)sig, (size_t)n * 4);
-    if (key == sigma_key) return 0;
-    if (n > sig_cap) {
+    if (key == t.key) return 0;
+    if (n > t.cap) {
         RALD_HIP(hipDeviceSynchronize());
-        for (void* p : {(void*)d_sigma, (void*)d_coef, (void*)d_cnoise, (void*)d_pe, (void*)d_temb0, (void*)d_temb, (void*)d_mod})
+        for (void* p : {(void*)t.sigma, (void*)t.coef, (void*)t.cnoise, (void*)t.pe, (void*)t.temb0, (void*)t.temb, (void*)t.mod})
             if (p) arena.release(p);
         const int cap = n < 64 ? 64 : n;
-        d_sigma = (float*)arena.alloc((size_t)cap * 4, true);
-        d_coef = (float*)arena.alloc((size_t)cap * 16, true);
-        d_cnoise = (float*)arena.alloc((size_t)cap * 4, true);
-        d_pe = (float*)arena.alloc((size_t)cap * cfg.t_channels * 4, true);
-        d_temb0 = (float*)arena.alloc((size_t)cap * D * 4, true);
-        d_temb = (float*)arena.alloc((size_t)cap * D * 4, true);
-        d_mod = (float*)arena.alloc((size_t)cap * mod_row() * 4, true);
-        RALD_CHECK(d_sigma && d_coef && d_cnoise && d_pe && d_temb0 && d_temb && d_mod, "dit: sigma table allocation failed");
-        sig_cap = cap;
+        t.sigma = (float*)arena.alloc((size_t)cap * 4, true);
+        t.coef = (float*)arena.alloc((size_t)cap * 16, true);
+        t.cnoise = (float*)arena.alloc((size_t)cap * 4, true);
+        t.pe = (float*)arena.alloc((size_t)cap * cfg.t_channels * 4, true);
+        t.temb0 = (float*)arena.alloc((size_t)cap * D * 4, true);
+        t.temb = (float*)arena.alloc((size_t)cap * D * 4, true);
+        t.mod = (float*)arena.alloc((size_t)cap * mod_row() * 4, true);
+        RALD_CHECK(t.sigma && t.coef && t.cnoise && t.pe && t.temb0 && t.temb && t.mod, "dit: sigma table allocation failed");
+        t.cap = cap;
     }
-    sigma_key.clear();
-    h_sigma.assign(sig, sig + n);   // the async copy below must not read a caller buffer that may go away
-    RALD_HIP(hipMemcpyAsync(d_sigma, h_sigma.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(edm_coef_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, d_sigma, d_coef, d_cnoise, n, cfg.sigma_data);
+    t.key.clear();
+    t.host.assign(sig, sig + n);   // the async copy below must not read a caller buffer that may go away
+    RALD_HIP(hipMemcpyAsync(t.sigma, t.host.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(edm_coef_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, t.sigma, t.coef, t.cnoise, n, cfg.sigma_data);
     RALD_HIP(hipGetLastError());
-    RALD_TRY(positional_embedding(d_cnoise, d_pe, n, cfg.t_channels, st));
-    RALD_TRY(skinny_linear(d_pe, w_t0, b_t0, d_temb0, n, D, cfg.t_channels, ACT_SILU, st));
-    RALD_TRY(skinny_linear(d_temb0, w_t1, b_t1, d_temb, n, D, D, ACT_SILU, st));
-    RALD_TRY(skinny_linear(d_temb, w_mod, b_mod, d_mod, n, (int)mod_row(), D, ACT_NONE, st));
-    sigma_key = key;
-    n_sigma = n;
+    RALD_TRY(positional_embedding(t.cnoise, t.pe, n, cfg.t_channels, st));
+    RALD_TRY(skinny_linear(t.pe, w_t0, b_t0, t.temb0, n, D, cfg.t_channels, ACT_SILU, st));
+    RALD_TRY(skinny_linear(t.temb0, w_t1, b_t1, t.temb, n, D, D, ACT_SILU, st));
+    RALD_TRY(skinny_linear(t.temb, w_mod, b_mod, t.mod, n, (int)mod_row(), D, ACT_NONE, st));
+    t.key = key;
+    t.n = n;
     return 0;
 }
+
+int Dit::set_sigmas(const float* sig, int n, hipStream_t st) { return build_table(tables[0], sig, n, st); }
 
 int64_t Dit::cond_cache_bytes(int B) const {
     // Kc [B*T][L*D] bf16  +  Vtc [B][L*D][T] bf16
@@ -337,18 +340,19 @@ int Dit::encode_cond(const float* cube, int B, float* out_tokens, void* cache, h
     return encode_cond_tokens(tok, B, cache, st);
 }
 
-int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const void* cache, float* out, int raw_F, hipStream_t st) {
+int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const void* cache, float* out, int raw_F, hipStream_t st, int slot) {
     RALD_CHECK(finalized, "dit: weights not finalized");
     RALD_CHECK(B >= 1 && x && out && cache, "dit: bad arguments");
-    RALD_CHECK(!sigma_key.empty(), "dit: rald_dit_set_sigmas has not been called");
-    RALD_CHECK(sigma_row >= 0 && sigma_row + (per_sample ? B : 1) <= n_sigma, "dit: sigma_row out of range of the sigma table");
+    const SigmaTable& tb = tables[slot];
+    RALD_CHECK(!tb.key.empty(), "dit: rald_dit_set_sigmas has not been called");
+    RALD_CHECK(sigma_row >= 0 && sigma_row + (per_sample ? B : 1) <= tb.n, "dit: sigma_row out of range of the sigma table");
     RALD_TRY(reserve(B));
     const int NL = cfg.n_latents, T = cfg.n_cond_tokens, L = cfg.depth, C = cfg.channels;
     const int M = B * NL;
     const int64_t mrow = mod_row();
-    const float* mod = d_mod + (int64_t)sigma_row * mrow;
+    const float* mod = tb.mod + (int64_t)sigma_row * mrow;
     const int64_t gstride = per_sample ? mrow : 0;
-    const float* coef = raw_F ? coef_raw : d_coef + 4 * (int64_t)sigma_row;
+    const float* coef = raw_F ? coef_raw : tb.coef + 4 * (int64_t)sigma_row;
     const int cstride = (per_sample && !raw_F) ? 4 : 0;
     const bf16* Kc = (const bf16*)cache;
     const bf16* Vtc = Kc + (size_t)B * T * L * D;
@@ -439,16 +443,16 @@ int Dit::sample(const float* latents, int B, const void* cache, int num_steps, f
     for (int i = 0; i < num_steps; ++i) t[i] = powf(a + (float)i / (float)(num_steps - 1) * (b - a), rho);
     t[num_steps] = 0.f;
     RALD_TRY(reserve(B));
-    RALD_TRY(set_sigmas(t.data(), num_steps, st));
+    RALD_TRY(build_table(tables[1], t.data(), num_steps, st));
     const int64_t n = (int64_t)B * cfg.n_latents * cfg.channels;
     RALD_TRY(scale_f32(latents, ws_xcur, t[0], n, st));                              // x_next = latents * t_0
     for (int i = 0; i < num_steps; ++i) {
         const float tc = t[i], tn = t[i + 1];
-        RALD_TRY(denoise(ws_xcur, B, i, 0, cache, ws_den, 0, st));                   // Euler step (:263-266)
+        RALD_TRY(denoise(ws_xcur, B, i, 0, cache, ws_den, 0, st, 1));                // Euler step (:263-266)
         const bool last = i == num_steps - 1;
         RALD_TRY(heun_euler(ws_xcur, ws_den, tc, tn, ws_dcur, last ? out : ws_xeul, n, st));
         if (!last) {                                                                 // 2nd-order correction (:269-273)
-            RALD_TRY(denoise(ws_xeul, B, i + 1, 0, cache, ws_den, 0, st));
+            RALD_TRY(denoise(ws_xeul, B, i + 1, 0, cache, ws_den, 0, st, 1));
             RALD_TRY(heun_correct(ws_xcur, ws_xeul, ws_den, ws_dcur, tc, tn, ws_xcur, n, st));   // in place, elementwise
         }
     }
