@@ -11,7 +11,7 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librald_hip.so")
+LIB_PATH = os.environ.get("RALD_LIB_OVERRIDE") or os.path.join(_HERE, "librald_hip.so")
 _lock = threading.Lock()
 _lib = None
 

@@ -42,12 +42,16 @@ __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
     const bf16* Q = a.Q + (int64_t)b * a.strideQ + (int64_t)(q0 + r) * a.ldq + h * 64 + 8 * hf;
 
     // DMA sources: piece p of this wave = tile rows 8*(wave + 4p) .. +7; lane -> (row l>>3, phys chunk l&7)
-    const int lr = lane >> 3, lc = (lane & 7) ^ lr;
+    // LDS swizzle: physical 16-byte chunk = logical chunk ^ ((row >> 1) & 7).  With 128-byte rows the
+    // 256-byte bank row holds two tile rows, so (row parity, chunk ^ f(row)) must be a bijection over
+    // the 16 rows a ds_read_b128 lane group touches: f = (row>>1)&7 is, f = row&7 is not (2-4-way).
+    const int lr = lane >> 3;
     const bf16* gK[2];
     const bf16* gV[2];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int row = 8 * (wave + 4 * p) + lr;
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);
         gK[p] = a.K + (int64_t)b * a.strideK + (int64_t)row * a.ldk + h * 64 + lc * 8;
         gV[p] = a.Vt + (int64_t)b * a.strideVt + (int64_t)(h * 64 + row) * a.ldvt + lc * 8;
     }
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
             const int krow = 32 * u + r;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + krow * 128 + (((2 * s + hf) ^ (krow & 7)) << 4));
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + krow * 128 + (((2 * s + hf) ^ ((krow >> 1) & 7)) << 4));
                 st[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[u], 0, 0, 0);
             }
         }
@@ -140,8 +144,8 @@ __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
                 for (int dt = 0; dt < 2; ++dt) {
                     const int vrow = 32 * dt + r;
                     const unsigned char* vr = sV + vrow * 128 + 8 * hf;
-                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vr + ((ch ^ (vrow & 7)) << 4));
-                    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vr + (((ch + 1) ^ (vrow & 7)) << 4));
+                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vr + ((ch ^ ((vrow >> 1) & 7)) << 4));
+                    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vr + (((ch + 1) ^ ((vrow >> 1) & 7)) << 4));
                     const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                     if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o0, 0, 0, 0);
                     else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o1, 0, 0, 0);

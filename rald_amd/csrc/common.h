@@ -65,6 +65,30 @@ __device__ __forceinline__ float erf_as(float x) {
 __device__ __forceinline__ float gelu_erf(float x) {   // erf GELU (F.gelu default, approximate='none')
     return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
 }
+// GELU for the GEGLU epilogue, two values at a time on packed fp32 ops (v_pk_mul/fma_f32), no
+// transcendental: erf(x/sqrt2) = xc * R(xc^2), xc = clamp(x, -3*sqrt2, 3*sqrt2), R = degree-8 minimax
+// fit (tools: fitted in float64, verified in fp32 Horner).  |gelu error| <= 4.5e-5 absolute, <= 0.4
+// bf16 ulp of the result wherever |gelu| > 0.01 - the epilogue rounds to bf16 right after.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) {
+    constexpr float L = 4.242640687f;
+    f32x2 xc;
+    xc[0] = __builtin_amdgcn_fmed3f(x[0], -L, L);
+    xc[1] = __builtin_amdgcn_fmed3f(x[1], -L, L);
+    const f32x2 s = xc * xc;
+    f32x2 r = f32x2{1.1252621139e-10f, 1.1252621139e-10f};
+    r = r * s + f32x2{-1.0743099887e-08f, -1.0743099887e-08f};
+    r = r * s + f32x2{4.5364107280e-07f, 4.5364107280e-07f};
+    r = r * s + f32x2{-1.1292158697e-05f, -1.1292158697e-05f};
+    r = r * s + f32x2{1.8717898050e-04f, 1.8717898050e-04f};
+    r = r * s + f32x2{-2.2187900973e-03f, -2.2187900973e-03f};
+    r = r * s + f32x2{1.9636213653e-02f, 1.9636213653e-02f};
+    r = r * s + f32x2{-1.3269382422e-01f, -1.3269382422e-01f};
+    r = r * s + f32x2{7.9780625133e-01f, 7.9780625133e-01f};
+    const f32x2 e = xc * r;                  // erf(x/sqrt2)
+    const f32x2 h = x * f32x2{0.5f, 0.5f};
+    return h * e + h;
+}
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
 __device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {

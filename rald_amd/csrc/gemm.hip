@@ -113,9 +113,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[MT][NT], const Ge
                 const float4 bx = *reinterpret_cast<const float4*>(a.bias + nx);
                 const float4 bg = *reinterpret_cast<const float4*>(a.bias + nx + 16);
                 const f32x4 x = acc[i][2 * p], g = acc[i][2 * p + 1];
-                *reinterpret_cast<bf16x4*>(patch + fr * STRIDE + (16 * p + 4 * fq) * 2) =
-                    pack4((x[0] + bx.x) * gelu_erf(g[0] + bg.x), (x[1] + bx.y) * gelu_erf(g[1] + bg.y),
-                          (x[2] + bx.z) * gelu_erf(g[2] + bg.z), (x[3] + bx.w) * gelu_erf(g[3] + bg.w));
+                const f32x2 g01 = gelu_poly2(f32x2{g[0] + bg.x, g[1] + bg.y});
+                const f32x2 g23 = gelu_poly2(f32x2{g[2] + bg.z, g[3] + bg.w});
+                const f32x2 o01 = f32x2{x[0] + bx.x, x[1] + bx.y} * g01;
+                const f32x2 o23 = f32x2{x[2] + bx.z, x[3] + bx.w} * g23;
+                *reinterpret_cast<bf16x4*>(patch + fr * STRIDE + (16 * p + 4 * fq) * 2) = pack4(o01[0], o01[1], o23[0], o23[1]);
             }
         } else {
 #pragma unroll
@@ -137,7 +139,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[MT][NT], const Ge
             const uint4 v = *reinterpret_cast<const uint4*>(patch + r * STRIDE + pc * 16);
             constexpr int EPP = F32OUT ? 4 : 8;                           // elements per 16-byte piece
             const int c = oc0 + pc * EPP;
-            if (m < a.M && c < ncols) {
+            if (m < a.M && c < ncols && !(a.ablate & 16)) {      // 16: diagnostics, no global stores
                 if constexpr (EPI == EPI_RESID) {
                     float* C = reinterpret_cast<float*>(a.C) + (int64_t)bz * a.strideC + (int64_t)m * a.ldc + c;
                     float4 x = *reinterpret_cast<float4*>(C);
