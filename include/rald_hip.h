@@ -144,6 +144,11 @@ int rald_op_layernorm(const float* x, void* out_bf16, int32_t M, int32_t D, cons
 int rald_op_attention(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK,
                       const void* Vt, int64_t ldvt, int64_t strideVt, void* O, int64_t ldo, int64_t strideO,
                       int32_t nq, int32_t nk, int32_t k_rows, int32_t heads, int32_t batch, float scale, void* stream);
+/* fused residual GEMM + next LayerNorm (N = 512): x[M][512] += A[M][K].W[512][K]^T + bias (fp32, in place);
+ * h_bf16 = LayerNorm(x) * (add_one + g[row/rows_per_group*gstride + c]) + b[...] */
+int rald_op_gemm_resid_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* x, void* h_bf16,
+                          const float* g, const float* b, int64_t gstride, int32_t rows_per_group, float add_one, float eps,
+                          int32_t M, int32_t K, void* stream);
 int rald_op_cast_bf16(const float* in, void* out_bf16, int64_t n, void* stream);
 
 #ifdef __cplusplus

@@ -205,6 +205,17 @@ def op_gemm_nt(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = 
     return out
 
 
+def op_gemm_resid_ln(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, x: torch.Tensor, g: torch.Tensor, b: torch.Tensor,
+                     gstride: int = 0, rows_per_group: int = 1 << 30, add_one: float = 0.0, eps: float = 1e-5) -> torch.Tensor:
+    """x [M,512] f32 += A [M,K] bf16 @ W [512,K]^T + bias (in place); returns h = LN(x)*(add_one+g)+b as bf16."""
+    M, K = A.shape
+    h = torch.empty(M, 512, device=A.device, dtype=torch.bfloat16)
+    check(lib().rald_op_gemm_resid_ln(C.c_void_p(_ptr(A)), A.stride(0), C.c_void_p(_ptr(W)), W.stride(0), C.c_void_p(_ptr(bias)),
+                                      C.c_void_p(_ptr(x)), C.c_void_p(_ptr(h)), C.c_void_p(_ptr(g)), C.c_void_p(_ptr(b)), gstride,
+                                      rows_per_group, add_one, eps, M, K, C.c_void_p(_stream())))
+    return h
+
+
 def op_layernorm(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, gstride: int = 0, rows_per_group: int = 1,
                  add_one: float = 0.0, eps: float = 1e-5) -> torch.Tensor:
     M, D = x.shape

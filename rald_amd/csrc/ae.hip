@@ -15,6 +15,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace rald {
@@ -363,9 +364,23 @@ int Ae::decode_latents(const float* z, int B, void* ctx, hipStream_t st) {
     const int M = cfg.num_latents, L = cfg.latent_dim, BM = B * M;
     const float scale = 1.0f / sqrtf((float)cfg.dim_head);
     RALD_TRY(small_k_linear(z, w_proj, b_proj, x_x, BM, L, d, st));                     // x = proj(z)  (:410)
-    for (const Layer& l : layers) {
-        // x = self_attn(x) + x                                                         (:413)
-        RALD_TRY(layernorm_mod(x_x, x_h, BM, d, l.ng, l.nb, 0, 1 << 30, 0.f, 1e-5f, st));
+    static const bool fuse_env = !(getenv("RALD_FUSE_LN") && atoi(getenv("RALD_FUSE_LN")) == 0);
+    const bool fuse_ln = fuse_env && d == 512 && gemm_resid_ln_pays(BM);   // the fused epilogue owns whole 512-wide rows
+    auto resid_ln = [&](const bf16* A, int64_t lda, const bf16* W, int64_t ldw, const float* bias, int K, const float* ng, const float* nb) -> int {
+        if (fuse_ln) {
+            GemmLnArgs g;
+            g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.x = x_x; g.h = x_h;
+            g.g = ng; g.b = nb; g.gstride = 0; g.rows_per_group = 1 << 30; g.add_one = 0.f; g.eps = 1e-5f; g.M = BM; g.K = K;
+            return gemm_resid_ln(g, st);
+        }
+        GemmArgs o = gemm_args(A, lda, W, ldw, x_x, d, bias, BM, d, K);
+        RALD_TRY(gemm_nt(o, EPI_RESID, st));
+        return layernorm_mod(x_x, x_h, BM, d, ng, nb, 0, 1 << 30, 0.f, 1e-5f, st);
+    };
+    RALD_TRY(layernorm_mod(x_x, x_h, BM, d, layers[0].ng, layers[0].nb, 0, 1 << 30, 0.f, 1e-5f, st));
+    for (size_t li = 0; li < layers.size(); ++li) {
+        const Layer& l = layers[li];
+        // x = self_attn(x) + x   (:413); LN(x) is already in x_h (prologue / previous layer's FF2 epilogue)
         GemmArgs qk = gemm_args(x_h, d, l.w_qk, d, x_qk, 2 * I, nullptr, BM, 2 * I, d);
         RALD_TRY(gemm_nt(qk, EPI_BF16, st));
         GemmArgs vt = gemm_args(l.w_v, d, x_h, d, x_vt, M, nullptr, I, M, d);
@@ -378,19 +393,18 @@ int Ae::decode_latents(const float* z, int B, void* ctx, hipStream_t st) {
         a.O = x_o; a.ldo = I; a.strideO = (int64_t)M * I;
         a.nq = M; a.nk = M; a.k_rows = M; a.heads = cfg.heads; a.batch = B; a.scale = scale;
         RALD_TRY(attention_d64(a, st));
-        GemmArgs o = gemm_args(x_o, I, l.w_o, I, x_x, d, l.b_o, BM, d, I);
-        RALD_TRY(gemm_nt(o, EPI_RESID, st));
+        RALD_TRY(resid_ln(x_o, I, l.w_o, I, l.b_o, I, l.ff.ng, l.ff.nb));             // + the FF's PreNorm
         // x = self_ff(x) + x                                                            (:414)
-        RALD_TRY(layernorm_mod(x_x, x_h, BM, d, l.ff.ng, l.ff.nb, 0, 1 << 30, 0.f, 1e-5f, st));
         GemmArgs f1 = gemm_args(x_h, d, l.ff.w1, d, x_g, 4 * d, l.ff.b1, BM, 8 * d, d);
         RALD_TRY(gemm_nt(f1, EPI_GEGLU, st));
-        GemmArgs f2 = gemm_args(x_g, 4 * d, l.ff.w2, 4 * d, x_x, d, l.ff.b2, BM, d, 4 * d);
-        RALD_TRY(gemm_nt(f2, EPI_RESID, st));
+        // FF2 + the next consumer's LayerNorm: next layer's attention PreNorm, or the decoder's norm_context
+        const float* ng = (li + 1 < layers.size()) ? layers[li + 1].ng : dec.cg;
+        const float* nb = (li + 1 < layers.size()) ? layers[li + 1].nb : dec.cb;
+        RALD_TRY(resid_ln(x_g, 4 * d, l.ff.w2, 4 * d, l.ff.b2, 4 * d, ng, nb));
     }
-    // decoder context: K = to_k(LN_ctx(x)); G = K.Wq (per sample); u = LN_ctx(x).w_fold
+    // decoder context: K = to_k(LN_ctx(x)) (LN_ctx(x) is in x_h); G = K.Wq (per sample); u = LN_ctx(x).w_fold
     bf16* G = (bf16*)ctx;
     float* u = (float*)((char*)ctx + (size_t)B * M * d * 2);
-    RALD_TRY(layernorm_mod(x_x, x_h, BM, d, dec.cg, dec.cb, 0, 1 << 30, 0.f, 1e-5f, st));
     GemmArgs kd = gemm_args(x_h, d, dec.w_k, d, x_kd, d, nullptr, BM, d, d);
     RALD_TRY(gemm_nt(kd, EPI_BF16, st));
     GemmArgs gg = gemm_args(x_kd, d, wq_dec_t, d, G, d, nullptr, BM, d, d);

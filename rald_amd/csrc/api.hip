@@ -137,6 +137,14 @@ int rald_op_attention(const void* Q, int64_t ldq, int64_t strideQ, const void* K
     a.nq = nq; a.nk = nk; a.k_rows = k_rows; a.heads = heads; a.batch = batch; a.scale = scale;
     return attention_d64(a, (hipStream_t)stream);
 }
+int rald_op_gemm_resid_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* x, void* h_bf16,
+                          const float* g, const float* b, int64_t gstride, int32_t rows_per_group, float add_one, float eps,
+                          int32_t M, int32_t K, void* stream) {
+    GemmLnArgs a;
+    a.A = (const bf16*)A; a.lda = lda; a.W = (const bf16*)W; a.ldw = ldw; a.bias = bias; a.x = x; a.h = (bf16*)h_bf16;
+    a.g = g; a.b = b; a.gstride = gstride; a.rows_per_group = rows_per_group; a.add_one = add_one; a.eps = eps; a.M = M; a.K = K;
+    return gemm_resid_ln(a, (hipStream_t)stream);
+}
 int rald_op_cast_bf16(const float* in, void* out_bf16, int64_t n, void* stream) {
     RALD_CHECK(in && out_bf16, "rald_op_cast_bf16: null pointer");
     return cast_f32_bf16(in, (bf16*)out_bf16, n, (hipStream_t)stream);

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace rald {
@@ -358,14 +359,32 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
     const bf16* Vtc = Kc + (size_t)B * T * L * D;
     const float scale = 1.0f / sqrtf((float)cfg.d_head);
 
+    // RALD_FUSE_LN=0 falls back to separate LayerNorm launches (A/B and debugging)
+    static const bool fuse_ln = !(getenv("RALD_FUSE_LN") && atoi(getenv("RALD_FUSE_LN")) == 0);
+    auto resid_ln = [&](const bf16* A, int64_t lda, const bf16* W, int64_t ldw, const float* bias, int K, const float* mnext) -> int {
+        // x += A.W^T + bias, then (if mnext) h = AdaLN(x; mnext) for the next sub-block
+        if (fuse_ln && mnext && gemm_resid_ln_pays(M)) {
+            GemmLnArgs g;
+            g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.x = ws_x; g.h = ws_h;
+            g.g = mnext; g.b = mnext + D; g.gstride = gstride; g.rows_per_group = NL; g.add_one = 1.0f; g.eps = 1e-5f;
+            g.M = M; g.K = K;
+            return gemm_resid_ln(g, st);
+        }
+        GemmArgs o = gemm_args(A, lda, W, ldw, ws_x, D, bias, M, D, K);
+        RALD_TRY(gemm_nt(o, EPI_RESID, st));
+        if (mnext) RALD_TRY(layernorm_mod(ws_x, ws_h, M, D, mnext, mnext + D, gstride, NL, 1.0f, 1e-5f, st));
+        return 0;
+    };
     RALD_TRY(proj_in(x, w_in, ws_x, M, C, D, coef, cstride, NL, st));
+    RALD_TRY(layernorm_mod(ws_x, ws_h, M, D, mod, mod + D, gstride, NL, 1.0f, 1e-5f, st));      // norm1 of block 0
     for (int li = 0; li < L; ++li) {
         const Layer& l = layers[li];
         const float* m1 = mod + (int64_t)(li * 3 + 0) * 2 * D;
         const float* m2 = mod + (int64_t)(li * 3 + 1) * 2 * D;
         const float* m3 = mod + (int64_t)(li * 3 + 2) * 2 * D;
         // ---- x += attn1(norm1(x, t))                                               (:166)
-        RALD_TRY(layernorm_mod(ws_x, ws_h, M, D, m1, m1 + D, gstride, NL, 1.0f, 1e-5f, st));
+        // (norm1(x) is already in ws_h: produced by the previous block's FF2 epilogue / the prologue)
+        (void)m1;
         GemmArgs qk = gemm_args(ws_h, D, l.w_qk, D, ws_qk, 2 * D, nullptr, M, 2 * D, D);
         RALD_TRY(gemm_nt(qk, EPI_BF16, st));
         GemmArgs vt = gemm_args(l.w_v, D, ws_h, D, ws_vt, NL, nullptr, D, NL, D);   // V^T = Wv . h^T per sample
@@ -378,10 +397,8 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
         a1.O = ws_o; a1.ldo = D; a1.strideO = (int64_t)NL * D;
         a1.nq = NL; a1.nk = NL; a1.k_rows = NL; a1.heads = cfg.n_heads; a1.batch = B; a1.scale = scale;
         RALD_TRY(attention_d64(a1, st));
-        GemmArgs o1 = gemm_args(ws_o, D, l.w_o, D, ws_x, D, l.b_o, M, D, D);
-        RALD_TRY(gemm_nt(o1, EPI_RESID, st));
+        RALD_TRY(resid_ln(ws_o, D, l.w_o, D, l.b_o, D, m2));                       // + norm2 for the next sub-block
         // ---- x += attn2(norm2(x, t), context)                                      (:167)
-        RALD_TRY(layernorm_mod(ws_x, ws_h, M, D, m2, m2 + D, gstride, NL, 1.0f, 1e-5f, st));
         GemmArgs q2 = gemm_args(ws_h, D, l.w_q2, D, ws_q2, D, nullptr, M, D, D);
         RALD_TRY(gemm_nt(q2, EPI_BF16, st));
         AttnArgs a2;
@@ -391,17 +408,15 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
         a2.O = ws_o; a2.ldo = D; a2.strideO = (int64_t)NL * D;
         a2.nq = NL; a2.nk = T; a2.k_rows = T; a2.heads = cfg.n_heads; a2.batch = B; a2.scale = scale;
         RALD_TRY(attention_d64(a2, st));
-        GemmArgs o2 = gemm_args(ws_o, D, l.w_o2, D, ws_x, D, l.b_o2, M, D, D);
-        RALD_TRY(gemm_nt(o2, EPI_RESID, st));
+        RALD_TRY(resid_ln(ws_o, D, l.w_o2, D, l.b_o2, D, m3));                     // + norm3
         // ---- x += ff(norm3(x, t))                                                   (:168)
-        RALD_TRY(layernorm_mod(ws_x, ws_h, M, D, m3, m3 + D, gstride, NL, 1.0f, 1e-5f, st));
         GemmArgs f1 = gemm_args(ws_h, D, l.w_ff1, D, ws_g, 4 * D, l.b_ff1, M, 8 * D, D);
         const bool timed = prof_on && prof_used + 2 <= (int)prof_ev.size();
         if (timed) RALD_HIP(hipEventRecord(prof_ev[prof_used], st));
         RALD_TRY(gemm_nt(f1, EPI_GEGLU, st));
         if (timed) { RALD_HIP(hipEventRecord(prof_ev[prof_used + 1], st)); prof_used += 2; }
-        GemmArgs f2 = gemm_args(ws_g, 4 * D, l.w_ff2, 4 * D, ws_x, D, l.b_ff2, M, D, 4 * D);
-        RALD_TRY(gemm_nt(f2, EPI_RESID, st));
+        const float* m1_next = (li + 1 < L) ? mod + (int64_t)((li + 1) * 3) * 2 * D : nullptr;   // norm1 of the next block
+        RALD_TRY(resid_ln(ws_g, 4 * D, l.w_ff2, 4 * D, l.b_ff2, 4 * D, m1_next));
     }
     RALD_TRY(final_norm_proj(ws_x, norm_g, norm_b, w_out, x, out, M, D, C, coef, cstride, NL, st));
     return 0;

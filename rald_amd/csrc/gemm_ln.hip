@@ -1,0 +1,223 @@
+// Residual GEMM with the NEXT LayerNorm fused into its epilogue (N = 512 = one full row per tile):
+//
+//     x[m][:]  += A[m][:] . W^T + bias                      (x = f(x) + x, fp32 residual stream)
+//     h[m][:]   = LN(x[m][:]) * (add_one + g[s][:]) + b[s][:]    (bf16, the next GEMM's A operand)
+//
+// i.e. `to_out(...) + x` followed by AdaLayerNorm / PreNorm-LayerNorm of the following sub-block
+// (models_radar_generation.py:166-168 + :127-131; models_ae.py:413-414 + :41-42).  Unfused, the
+// LayerNorm is a separate HBM-bound pass that re-reads the 4-byte stream; fused, x is read once
+// and written once per sub-block and three launches per transformer block disappear.
+//
+// Tile BM x 512 x 64, 8 waves as WM x WN, LDS-DMA staged double buffer (same engine as
+// gemm_nt_glds_kernel; at BM = 128 the two stages take exactly the CU's 160 KiB).  Epilogue:
+//   1. v = acc + bias + x_old in the accumulator layout (lane: 4 columns of 16 rows per m-tile);
+//   2. per-row sum / sum-of-squares: 32 in-lane values, 2 cross-lane steps, then across the WN waves
+//      through a 4 KiB LDS table and ONE workgroup barrier (single-pass variance in fp32: 512 terms);
+//   3. x_new and h leave through the wave-private LDS transpose as whole rows (16 B per lane).
+#include "common.h"
+#include "kernels.h"
+
+namespace rald {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+template <int BM, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs a) {
+    constexpr int BN = 512, BK = 64, NSTAGE = 2;
+    constexpr int WAVES = WM * WN;
+    constexpr int MT = BM / (16 * WM);
+    constexpr int NT = BN / (16 * WN);
+    constexpr int CA = BM / 8 / WAVES;
+    constexpr int CB = BN / 8 / WAVES;
+    static_assert(CA >= 1 && CB >= 1 && MT >= 1 && NT >= 1, "tile/wave split");
+    constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
+    constexpr int ROWB_F = NT * 16 * 4, STRIDE_F = ROWB_F + 16;      // fp32 patch row (x_new)
+    constexpr int ROWB_H = NT * 16 * 2, STRIDE_H = ROWB_H + 16;      // bf16 patch row (h)
+    constexpr int PATCH = 16 * STRIDE_F;
+    constexpr int RED_OFF = WAVES * PATCH;                            // float2 red[BM][WN]
+    static_assert(RED_OFF + BM * WN * 8 <= NSTAGE * STAGE_BYTES, "epilogue scratch must fit in the staging buffers");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM;
+    const int lr = lane >> 3;
+    const int lc = (lane & 7) ^ lr;
+    const bf16* gA[CA];
+    const bf16* gB[CB];
+#pragma unroll
+    for (int p = 0; p < CA; ++p) {
+        int r = m0 + 8 * (wave + WAVES * p) + lr;
+        r = r < a.M ? r : a.M - 1;
+        gA[p] = a.A + (int64_t)r * a.lda + lc * 8;
+    }
+#pragma unroll
+    for (int p = 0; p < CB; ++p) gB[p] = a.W + (int64_t)(8 * (wave + WAVES * p) + lr) * a.ldw + lc * 8;
+    auto stage = [&](int kt, int buf) {
+        unsigned char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int p = 0; p < CA; ++p)
+            __builtin_amdgcn_global_load_lds((glb_void*)(gA[p] + kt * BK), (lds_void*)(base + (wave + WAVES * p) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int p = 0; p < CB; ++p)
+            __builtin_amdgcn_global_load_lds((glb_void*)(gB[p] + kt * BK), (lds_void*)(base + BM * 128 + (wave + WAVES * p) * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk = a.K / BK;
+    const int fr = lane & 15, fq = lane >> 4;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        const bf16x8* sA = reinterpret_cast<const bf16x8*>(smem + (kt & 1) * STAGE_BYTES);
+        const bf16x8* sB = sA + BM * 8;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[MT], fb[NT];
+            const int chunk = kk * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int r = wm * (BM / WM) + i * 16 + fr;
+                fa[i] = sA[r * 8 + (chunk ^ (r & 7))];
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int r = wn * (BN / WN) + j * 16 + fr;
+                fb[j] = sB[r * 8 + (chunk ^ (r & 7))];
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- 1. v = acc + bias + x_old (accumulator layout), row partial sums -------------------------
+    const int mb = m0 + wm * (BM / WM);
+    const int nb = wn * (BN / WN);
+    float s1[MT], s2[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int m = mb + i * 16 + fr;
+        m = m < a.M ? m : a.M - 1;
+        s1[i] = 0.f; s2[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = nb + j * 16 + 4 * fq;
+            const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+            const float4 xo = *reinterpret_cast<const float4*>(a.x + (int64_t)m * BN + n);
+            f32x4 v = acc[i][j];
+            v[0] += b.x + xo.x; v[1] += b.y + xo.y; v[2] += b.z + xo.z; v[3] += b.w + xo.w;
+            acc[i][j] = v;
+            s1[i] += (v[0] + v[1]) + (v[2] + v[3]);
+            s2[i] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+        s1[i] += __shfl_xor(s1[i], 16, 64); s2[i] += __shfl_xor(s2[i], 16, 64);
+        s1[i] += __shfl_xor(s1[i], 32, 64); s2[i] += __shfl_xor(s2[i], 32, 64);
+        asm volatile("" ::: "memory");            // keep only one m-tile's x_old loads in flight (register pressure)
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();                 // staging buffers are dead: reuse them (patches + red)
+    asm volatile("" ::: "memory");
+    float2* red = reinterpret_cast<float2*>(smem + RED_OFF);
+    if (fq == 0) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) red[(wm * (BM / WM) + i * 16 + fr) * WN + wn] = make_float2(s1[i], s2[i]);
+    }
+    __syncthreads();
+    float mean[MT], rstd[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WN; ++w) {
+            const float2 p = red[(wm * (BM / WM) + i * 16 + fr) * WN + w];
+            t1 += p.x; t2 += p.y;
+        }
+        mean[i] = t1 * (1.0f / BN);
+        const float var = fmaxf(t2 * (1.0f / BN) - mean[i] * mean[i], 0.f);
+        rstd[i] = rsqrtf(var + a.eps);
+    }
+
+    // ---- 2. x_new (fp32) and h (bf16) out as whole rows through the wave-private patch -------------
+    unsigned char* patch = smem + wave * PATCH;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        // x_new
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            *reinterpret_cast<float4*>(patch + fr * STRIDE_F + (16 * j + 4 * fq) * 4) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        {
+            constexpr int LPR = ROWB_F / 16, RPI = 64 / LPR;
+#pragma unroll
+            for (int r0 = 0; r0 < 16; r0 += RPI) {
+                const int r = r0 + lane / LPR, pc = lane % LPR;
+                const int m = mb + i * 16 + r;
+                const uint4 v = *reinterpret_cast<const uint4*>(patch + r * STRIDE_F + pc * 16);
+                if (m < a.M) *reinterpret_cast<uint4*>(a.x + (int64_t)m * BN + nb + pc * 4) = v;
+            }
+        }
+        // h = (v - mean) * rstd * (add_one + g) + b ; modulation row of this row's sample
+        int m = mb + i * 16 + fr;
+        m = m < a.M ? m : a.M - 1;
+        const int64_t goff = (int64_t)(m / a.rows_per_group) * a.gstride;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = nb + j * 16 + 4 * fq;
+            const float4 gg = *reinterpret_cast<const float4*>(a.g + goff + n);
+            const float4 bb = *reinterpret_cast<const float4*>(a.b + goff + n);
+            const f32x4 v = acc[i][j];
+            *reinterpret_cast<bf16x4*>(patch + fr * STRIDE_H + (16 * j + 4 * fq) * 2) =
+                pack4((v[0] - mean[i]) * rstd[i] * (a.add_one + gg.x) + bb.x, (v[1] - mean[i]) * rstd[i] * (a.add_one + gg.y) + bb.y,
+                      (v[2] - mean[i]) * rstd[i] * (a.add_one + gg.z) + bb.z, (v[3] - mean[i]) * rstd[i] * (a.add_one + gg.w) + bb.w);
+        }
+        {
+            constexpr int LPR = ROWB_H / 16, RPI = 64 / LPR;
+#pragma unroll
+            for (int r0 = 0; r0 < 16; r0 += RPI) {
+                const int r = r0 + lane / LPR, pc = lane % LPR;
+                const int mm = mb + i * 16 + r;
+                const uint4 v = *reinterpret_cast<const uint4*>(patch + r * STRIDE_H + pc * 16);
+                if (mm < a.M) *reinterpret_cast<uint4*>(a.h + (int64_t)mm * BN + nb + pc * 8) = v;
+            }
+        }
+    }
+}
+
+template <int BM, int WM, int WN>
+static int launch_ln(const GemmLnArgs& a, hipStream_t st) {
+    constexpr int smem = 2 * (BM + 512) * 64 * 2;
+    static bool attr_set = false;
+    auto kern = gemm_resid_ln_kernel<BM, WM, WN>;
+    if (!attr_set) {
+        RALD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(cdiv(a.M, BM)), dim3(WM * WN * 64), smem, st, a);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+int gemm_resid_ln(const GemmLnArgs& a, hipStream_t st) {
+    RALD_CHECK(a.M > 0 && a.K > 0 && a.K % 64 == 0, "gemm_resid_ln: bad shape");
+    RALD_CHECK(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.lda >= a.K && a.ldw >= a.K, "gemm_resid_ln: leading dimensions");
+    RALD_CHECK(a.A && a.W && a.bias && a.x && a.h && a.g && a.b && a.rows_per_group > 0, "gemm_resid_ln: null argument");
+    RALD_CHECK(((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.W % 16 == 0) && ((uintptr_t)a.x % 16 == 0) && ((uintptr_t)a.h % 16 == 0) &&
+               ((uintptr_t)a.g % 16 == 0) && ((uintptr_t)a.b % 16 == 0) && a.gstride % 4 == 0, "gemm_resid_ln: 16-byte alignment");
+    // 128-row tiles (all 160 KiB of LDS) when they cover the chip, 64-row tiles for smaller M
+    if (cdiv(a.M, 128) >= 192) return launch_ln<128, 2, 4>(a, st);
+    return launch_ln<64, 1, 8>(a, st);
+}
+
+}  // namespace rald

@@ -24,6 +24,21 @@ inline GemmArgs gemm_args(const bf16* A, int64_t lda, const bf16* B, int64_t ldb
     return g;
 }
 
+// ---------------------------------------------------------------- gemm_ln.hip
+// x[M][512] += A[M][K].W[512][K]^T + bias ;  h = LN(x) * (add_one + g[s]) + b[s]  (s = row / rows_per_group * gstride)
+struct GemmLnArgs {
+    const bf16* A; int64_t lda;
+    const bf16* W; int64_t ldw;
+    const float* bias;
+    float* x;                 // [M][512] fp32, updated in place
+    bf16* h;                  // [M][512] bf16 out
+    const float* g; const float* b; int64_t gstride; int rows_per_group; float add_one, eps;
+    int M, K;
+};
+int gemm_resid_ln(const GemmLnArgs& a, hipStream_t st);
+// true when the fused kernel beats GEMM + separate LayerNorm (its 128-row tiles must cover the chip; measured on MI355X)
+inline bool gemm_resid_ln_pays(int M) { return M >= 192 * 128; }
+
 // ---------------------------------------------------------------- norm.hip
 // out_bf16[m][c] = LN(x[m])[c] * (add_one + g[s][c]) + b[s][c],  s = (m / rows_per_group) * gstride
 int layernorm_mod(const float* x, bf16* out, int M, int D, const float* g, const float* b,

@@ -131,3 +131,22 @@ def test_attention_exact_one_hot(H):
     vt = torch.zeros(B, 64, nkp); vt[:, :, :nk] = v.transpose(1, 2)
     out = H.op_attention(q.cuda().bfloat16(), kp.cuda().bfloat16(), vt.cuda().bfloat16(), nk, heads, 1.0)
     assert torch.equal(out.float().cpu()[0], v[0, sel])
+
+
+@pytest.mark.parametrize("M,K", [(512, 512), (1000, 2048), (32768, 512), (32768, 2048)])
+def test_gemm_residual_with_fused_layernorm(H, M, K):
+    """x += A.W^T + bias and the next (Ada)LayerNorm in one kernel: both outputs against fp32 torch,
+    with per-group modulation rows (AdaLN, add_one = 1) - 64-row and 128-row tile configurations."""
+    A = torch.randn(M, K, device="cuda").bfloat16()
+    W = (torch.randn(512, K, device="cuda") / K ** 0.5).bfloat16()
+    bias = torch.randn(512, device="cuda")
+    x = torch.randn(M, 512, device="cuda") * 2 + 0.5
+    rpg = 250
+    ngrp = (M + rpg - 1) // rpg
+    mod = torch.randn(ngrp, 1024, device="cuda")
+    xref = x + A.float() @ W.float().t() + bias
+    grp = torch.arange(M, device="cuda") // rpg
+    href = torch.nn.functional.layer_norm(xref, (512,)) * (1 + mod[grp, :512]) + mod[grp, 512:]
+    h = H.op_gemm_resid_ln(A, W, bias, x, mod, mod[:, 512:], gstride=1024, rows_per_group=rpg, add_one=1.0)
+    assert rel_l2(x, xref) < 2e-6
+    assert rel_l2(h, href) < 4e-3
