@@ -130,6 +130,19 @@ int rald_ae_decode_queries(rald_ae* h, const void* ctx, const float* queries, in
                            float* out_logits, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Radar-spectrum encoder alone: RadarAutoencoder.encoder / _encode (model/models_radar_encoder.py
+ * :137-241, :390-393) - the frozen-encoder route of engine_generation.py:87, :191.  Keys are
+ * those BELOW "encoder." in a RadarAutoencoder checkpoint.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct rald_radar rald_radar;
+int rald_radar_create(int32_t basic_channel, int32_t embed_dim, int32_t in_channels, int32_t R, int32_t A, int32_t E, rald_radar** out);
+void rald_radar_destroy(rald_radar* h);
+int rald_radar_load_weight(rald_radar* h, const char* name, const float* data, int64_t nelem);
+int rald_radar_finalize(rald_radar* h);
+/* cube [B,R,A,E,in_channels] -> z [B,R/16,A/16,E/16,embed_dim]  (= _encode's permuted output) */
+int rald_radar_encode(rald_radar* h, const float* cube, int32_t batch, float* out_z, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Kernel-level entry points (what the parity tests and microbenchmarks drive directly)
  * ---------------------------------------------------------------------------------------- */
 /* C[b][m][n] = alpha * sum_k A[b][m][k]*B[b][n][k] (+bias[n]); A,B bf16 (K contiguous).

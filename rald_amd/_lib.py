@@ -58,6 +58,11 @@ SIGNATURES = {
     "rald_ae_ctx_bytes": (c_i64, [c_void_p, c_int]),
     "rald_ae_decode_latents": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "rald_ae_decode_queries": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_void_p, c_void_p]),
+    "rald_radar_create": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, C.POINTER(c_void_p)]),
+    "rald_radar_destroy": (None, [c_void_p]),
+    "rald_radar_load_weight": (c_int, [c_void_p, c_char_p, c_void_p, c_i64]),
+    "rald_radar_finalize": (c_int, [c_void_p]),
+    "rald_radar_encode": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "rald_op_gemm_nt": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p,
                                 c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "rald_op_layernorm": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_i64, c_int, c_float, c_float, c_void_p]),

@@ -111,6 +111,41 @@ int rald_ae_decode_queries(rald_ae* h, const void* ctx, const float* queries, in
     return h->impl.decode_queries(ctx, queries, batch, n_queries, out_logits, (hipStream_t)stream);
 }
 
+// ---- standalone radar-spectrum encoder (RadarAutoencoder.encoder) -------------------------------
+struct rald_radar { DeviceArena arena; Stager stager; RadarEncoder enc; int R, A, E, cin, zc; };
+int rald_radar_create(int32_t basic_channel, int32_t embed_dim, int32_t in_channels, int32_t R, int32_t A, int32_t E, rald_radar** out) {
+    RALD_CHECK(out, "rald_radar_create: null argument");
+    rald_radar* h = new rald_radar();
+    h->R = R; h->A = A; h->E = E; h->cin = in_channels; h->zc = embed_dim;
+    int rc = h->enc.create(basic_channel, embed_dim, R, A, E, 512, &h->arena, in_channels);
+    if (rc) { delete h; return rc; }
+    *out = h;
+    return 0;
+}
+void rald_radar_destroy(rald_radar* h) {
+    if (!h) return;
+    (void)hipDeviceSynchronize();
+    delete h;
+}
+int rald_radar_load_weight(rald_radar* h, const char* name, const float* data, int64_t nelem) {
+    RALD_CHECK(h && name && data, "rald_radar_load_weight: null argument");
+    return h->enc.load_weight(name, data, nelem, h->stager);
+}
+int rald_radar_finalize(rald_radar* h) {
+    RALD_CHECK(h, "null handle");
+    std::string missing;
+    RALD_CHECK(h->enc.all_loaded(&missing), "radar encoder: missing key '" + missing + "' (strict load)");
+    return 0;
+}
+int rald_radar_encode(rald_radar* h, const float* cube, int32_t batch, float* out_z, void* stream) {
+    RALD_CHECK(h && cube && out_z && batch >= 1, "rald_radar_encode: bad argument");
+    float* z = nullptr;
+    RALD_TRY(h->enc.encode(cube, h->cin, batch, &z, (hipStream_t)stream));
+    const size_t n = (size_t)batch * (h->R / 16) * (h->A / 16) * (h->E / 16) * h->zc;
+    RALD_HIP(hipMemcpyAsync(out_z, z, n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
 // ---- kernel-level entry points -----------------------------------------------------------------
 int rald_op_gemm_nt(const void* A, int64_t lda, int64_t strideA, const void* B, int64_t ldb, int64_t strideB,
                     void* C, int64_t ldc, int64_t strideC, const float* bias, int32_t M, int32_t N, int32_t K,

@@ -36,7 +36,8 @@ std::vector<int> geglu_rowmap(int inner);
 struct RadarEncoder {
     struct Impl;
     Impl* impl = nullptr;
-    int create(int ch, int z_ch, int R, int A, int E, int token_ch, DeviceArena* arena);
+    int create(int ch, int z_ch, int R, int A, int E, int token_ch, DeviceArena* arena, int in_channels = 1);
+    bool all_loaded(std::string* missing) const;
     void expected_keys(const std::string& prefix, std::set<std::string>& out) const;
     int load_weight(const std::string& name, const float* data, int64_t nelem, Stager& st);        // keys below "radar_enc."
     int load_token_weight(const std::string& name, const float* data, int64_t nelem, Stager& st);  // radar_*_emb / radar_token_project

@@ -22,13 +22,13 @@ namespace rald {
 // kernels
 // ------------------------------------------------------------------------------------------------
 // conv_in: Cin = 1 -> ch (64); the cube's channel 0 is read in place ([B,R,A,E,cube_ch], :378).
-__global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ cube, int cube_ch, const float* __restrict__ W,
+__global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ cube, int cube_ch, int Cin, const float* __restrict__ W,
                                                       const float* __restrict__ bias, float* __restrict__ out, int B, int D,
                                                       int H, int Wd, int Cout) {
-    extern __shared__ float sw[];            // [27][Cout] (tap-major so 8 consecutive co are contiguous)
-    for (int i = threadIdx.x; i < 27 * Cout; i += 256) {
-        const int t = i / Cout, co = i % Cout;
-        sw[i] = W[co * 27 + t];
+    extern __shared__ float sw[];            // [Cin][27][Cout] (tap-major so 8 consecutive co are contiguous)
+    for (int i = threadIdx.x; i < Cin * 27 * Cout; i += 256) {
+        const int co = i % Cout, t = (i / Cout) % 27, ci = i / (27 * Cout);
+        sw[i] = W[(co * Cin + ci) * 27 + t];
     }
     __syncthreads();
     const int groups = Cout / 8;                          // threads per voxel
@@ -50,10 +50,13 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
             for (int kw = 0; kw < 3; ++kw) {
                 const int id = d + kd - 1, ih = h + kh - 1, iw = w + kw - 1;
                 if ((unsigned)id >= (unsigned)D || (unsigned)ih >= (unsigned)H || (unsigned)iw >= (unsigned)Wd) continue;
-                const float x = cube[((((int64_t)b * D + id) * H + ih) * Wd + iw) * cube_ch];
-                const float* wt = sw + ((kd * 3 + kh) * 3 + kw) * Cout + cg * 8;
+                const float* xp = cube + ((((int64_t)b * D + id) * H + ih) * Wd + iw) * cube_ch;
+                for (int ci = 0; ci < Cin; ++ci) {
+                    const float x = xp[ci];
+                    const float* wt = sw + (ci * 27 + (kd * 3 + kh) * 3 + kw) * Cout + cg * 8;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] += x * wt[i];
+                    for (int i = 0; i < 8; ++i) acc[i] += x * wt[i];
+                }
             }
     float4* o = reinterpret_cast<float4*>(out + v * Cout + cg * 8);
     o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -276,7 +279,7 @@ __global__ void radar_token_kernel(const float* __restrict__ z, const float* __r
 // host side
 // ------------------------------------------------------------------------------------------------
 struct RadarEncoder::Impl {
-    int ch = 64, zc = 16, R = 128, A = 64, E = 32, token_ch = 512;
+    int ch = 64, zc = 16, R = 128, A = 64, E = 32, token_ch = 512, cin = 1;
     DeviceArena* arena = nullptr;
     enum Kind { CONV3, CONV1, VEC, CONVIN };
     struct Tensor { Kind kind; int cout, cin; void* ptr = nullptr; bool loaded = false; };
@@ -316,14 +319,15 @@ struct RadarEncoder::Impl {
 
 static const int kChMult[5] = {1, 1, 2, 2, 4};
 
-int RadarEncoder::create(int ch, int z_ch, int R, int A, int E, int token_ch, DeviceArena* arena) {
+int RadarEncoder::create(int ch, int z_ch, int R, int A, int E, int token_ch, DeviceArena* arena, int in_channels) {
+    RALD_CHECK(in_channels == 1 || in_channels == 2, "radar encoder: in_channels must be 1 or 2");
     RALD_CHECK(ch % 64 == 0 && ch >= 64, "radar encoder: hidden channels must be a multiple of 64");
     RALD_CHECK(R % 16 == 0 && A % 16 == 0 && E % 16 == 0, "radar encoder: cube dims must be multiples of 16");
     RALD_CHECK(z_ch % 4 == 0 && z_ch <= 64, "radar encoder: z channels must be a multiple of 4, <= 64");
     impl = new Impl();
     Impl& m = *impl;
-    m.ch = ch; m.zc = z_ch; m.R = R; m.A = A; m.E = E; m.token_ch = token_ch; m.arena = arena;
-    m.add("conv_in.weight", Impl::CONVIN, ch, 1);
+    m.ch = ch; m.zc = z_ch; m.R = R; m.A = A; m.E = E; m.token_ch = token_ch; m.arena = arena; m.cin = in_channels;
+    m.add("conv_in.weight", Impl::CONVIN, ch, in_channels);
     m.add("conv_in.bias", Impl::VEC, ch, 0);
     int block_in = ch;
     for (int l = 0; l < 5; ++l) {
@@ -349,7 +353,7 @@ int RadarEncoder::create(int ch, int z_ch, int R, int A, int E, int token_ch, De
             case Impl::CONV3: bytes = (size_t)t.cout * 27 * t.cin * 2; break;
             case Impl::CONV1: bytes = (size_t)t.cout * t.cin * 2; break;
             case Impl::VEC: bytes = (size_t)t.cout * 4; break;
-            case Impl::CONVIN: bytes = (size_t)t.cout * 27 * 4; break;
+            case Impl::CONVIN: bytes = (size_t)t.cout * t.cin * 27 * 4; break;
         }
         t.ptr = arena->alloc(bytes < 64 ? 64 : bytes, true);       // >= 16 floats so float4 bias reads of a 16-ch tail stay in bounds
         RALD_CHECK(t.ptr, "radar encoder: weight allocation failed");
@@ -362,6 +366,13 @@ int RadarEncoder::create(int ch, int z_ch, int R, int A, int E, int token_ch, De
     m.emb_e = (float*)arena->alloc((size_t)nt_e * token_ch * 4, true);
     RALD_CHECK(m.w_tok && m.b_tok && m.emb_r && m.emb_a && m.emb_e, "radar encoder: allocation failed");
     return 0;
+}
+
+bool RadarEncoder::all_loaded(std::string* missing) const {
+    if (!impl) return false;
+    for (const auto& kv : impl->tensors)
+        if (!kv.second.loaded) { if (missing) *missing = kv.first; return false; }
+    return true;
 }
 
 void RadarEncoder::expected_keys(const std::string& prefix, std::set<std::string>& out) const {
@@ -380,8 +391,8 @@ int RadarEncoder::load_weight(const std::string& name, const float* data, int64_
             RALD_TRY(st.to_f32(data, (float*)t.ptr, 1, t.cout, t.cout, nullptr));
             break;
         case Impl::CONVIN:
-            RALD_CHECK(nelem == (int64_t)t.cout * 27, "radar encoder: size mismatch for '" + name + "'");
-            RALD_TRY(st.to_f32(data, (float*)t.ptr, t.cout, 27, 27, nullptr));
+            RALD_CHECK(nelem == (int64_t)t.cout * t.cin * 27, "radar encoder: size mismatch for '" + name + "'");
+            RALD_TRY(st.to_f32(data, (float*)t.ptr, t.cout, t.cin * 27, t.cin * 27, nullptr));
             break;
         case Impl::CONV1:
             RALD_CHECK(nelem == (int64_t)t.cout * t.cin, "radar encoder: size mismatch for '" + name + "'");
@@ -517,7 +528,8 @@ int RadarEncoder::Impl::forward(const float* cube, int cube_ch, int B, float* zo
     {
         const int groups = ch / 8, vpb = 256 / groups;
         const int64_t nvox = (int64_t)B * Dd * Hh * Ww;
-        hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)((nvox + vpb - 1) / vpb)), dim3(256), 27 * ch * 4, st, cube, cube_ch,
+        RALD_CHECK(cube_ch >= cin, "radar encoder: cube has fewer channels than conv_in expects");
+        hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)((nvox + vpb - 1) / vpb)), dim3(256), cin * 27 * ch * 4, st, cube, cube_ch, cin,
                            P<float>("conv_in.weight"), P<float>("conv_in.bias"), x, B, Dd, Hh, Ww, ch);
         RALD_HIP(hipGetLastError());
     }

@@ -79,6 +79,63 @@ def radar_encoder_spec(prefix: str = "radar_enc.", ch: int = 64, in_channels: in
     return s
 
 
+def radar_decoder_spec(prefix: str = "decoder.", ch: int = 64, out_ch: int = 2, z_channels: int = 16,
+                       ch_mult: Sequence[int] = (1, 1, 2, 2, 4), num_res_blocks: int = 2) -> Spec:
+    """models_radar_encoder.py:243-332 (Decoder.__init__; attn_resolutions=() so only mid.attn_1).
+    `up` is built from the last level down but stored by level index (insert(0), :326)."""
+    s: Spec = []
+
+    def conv(name, cout, cin, k):
+        s.append((f"{prefix}{name}.weight", (cout, cin, k, k, k)))
+        s.append((f"{prefix}{name}.bias", (cout,)))
+
+    def norm(name, c):
+        s.append((f"{prefix}{name}.weight", (c,)))
+        s.append((f"{prefix}{name}.bias", (c,)))
+
+    def resblock(name, cin, cout):
+        norm(f"{name}.norm1", cin)
+        conv(f"{name}.conv1", cout, cin, 3)
+        norm(f"{name}.norm2", cout)
+        conv(f"{name}.conv2", cout, cout, 3)
+        if cin != cout:
+            conv(f"{name}.nin_shortcut", cout, cin, 1)
+
+    nlev = len(ch_mult)
+    block_in = ch * ch_mult[-1]
+    conv("conv_in", block_in, z_channels, 3)
+    resblock("mid.block_1", block_in, block_in)
+    norm("mid.attn_1.norm", block_in)
+    for p in ("q", "k", "v", "proj_out"):
+        conv(f"mid.attn_1.{p}", block_in, block_in, 1)
+    resblock("mid.block_2", block_in, block_in)
+    ups = {}
+    for lvl in reversed(range(nlev)):
+        start = len(s)
+        block_out = ch * ch_mult[lvl]
+        for b in range(num_res_blocks + 1):
+            resblock(f"up.{lvl}.block.{b}", block_in, block_out)
+            block_in = block_out
+        if lvl != 0:
+            conv(f"up.{lvl}.upsample.conv", block_in, block_in, 3)
+        ups[lvl] = s[start:]
+        del s[start:]
+    for lvl in range(nlev):
+        s.extend(ups[lvl])
+    norm("norm_out", block_in)
+    conv("conv_out", out_ch, block_in, 3)
+    return s
+
+
+def radar_autoencoder_spec(basic_channel: int = 64, embed_dim: int = 16, ch_mult: Sequence[int] = (1, 1, 2, 2, 4),
+                           num_res_blocks: int = 2) -> Spec:
+    """RadarAutoencoder (models_radar_encoder.py:366-379): Encoder(in_channels=2 default) + Decoder."""
+    return (radar_encoder_spec("encoder.", ch=basic_channel, in_channels=2, z_channels=embed_dim, ch_mult=ch_mult,
+                               num_res_blocks=num_res_blocks)
+            + radar_decoder_spec("decoder.", ch=basic_channel, out_ch=2, z_channels=embed_dim, ch_mult=ch_mult,
+                                 num_res_blocks=num_res_blocks))
+
+
 def dit_spec(channels: int = 32, depth: int = 24, n_heads: int = 8, d_head: int = 64,
              t_channels: int = 256, context_dim: int | None = None,
              with_radar: bool = True, enc_hidden_ch: int = 64, enc_radar_ch: int = 16,

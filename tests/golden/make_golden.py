@@ -234,3 +234,21 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def golden_radar_autoencoder():
+    """G8: RadarAutoencoder._encode (models_radar_encoder.py:390-393), ae_ch64_mult5_n2_d16."""
+    G, A, R = import_reference()
+    import contextlib, io
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        m = R.ae_ch64_mult5_n2_d16()
+    spec = seed_module(m, 0)
+    with open(os.path.join(HERE, "state_dict_keys_radar_ae.json"), "w") as f:
+        json.dump({"ae_ch64_mult5_n2_d16": spec}, f)
+    with torch.no_grad():
+        z = m._encode(synth.radar_cube(2))
+    save("g8_radar_autoencoder.npz", z=z)
+
+
+if __name__ == "__main__" and "--g8" in sys.argv:
+    pass

@@ -101,3 +101,35 @@ def test_graph_replay_equals_eager_launches():
         a = ha.decode_queries(ha.decode_latents(z, use_graph=False), q)
         b = ha.decode_queries(ha.decode_latents(z, use_graph=True), q)
         assert torch.equal(a, b)
+
+
+def test_radar_autoencoder_encode_vs_reference_golden():
+    """RadarAutoencoder._encode (frozen-encoder route, in_channels = 2), ae_ch64_mult5_n2_d16."""
+    from rald_amd import models_radar_encoder as R, synth, weights
+    m = R.__dict__["ae_ch64_mult5_n2_d16"]()
+    m.load_state_dict(weights.make_state_dict(weights.radar_autoencoder_spec(64), 0), strict=True)
+    m = m.cuda()
+    g = load_golden("g8_radar_autoencoder.npz")
+    z = m._encode(synth.radar_cube(2).cuda())
+    print("radar AE _encode rel_l2", rel_l2(z, g["z"]))
+    assert z.shape == (2, 8, 4, 2, 16)
+    assert rel_l2(z, g["z"]) < 1.5e-2
+    with pytest.raises(NotImplementedError):
+        m(synth.radar_cube(1).cuda())
+
+
+def test_edm_loss_forward_value_vs_reference_golden(monkeypatch):
+    """EDMLoss.__call__ (models_radar_generation.py:283-295), depth-2 model: the two random draws
+    are replaced by the ones the reference consumed (recorded in the golden), so the loss value must
+    match the reference's.  (The backward pass is SURVEY.md §8f rank 1 - next.)"""
+    from rald_amd import models_radar_generation as G, synth
+    g = load_golden("g6_edmloss.npz")
+    m = _edm(2)
+    y = synth.normal([2, 512, 32], 21).cuda()
+    cube = synth.radar_cube(2).cuda()
+    monkeypatch.setattr(torch, "randn", lambda *a, **k: g["rnd_normal"].cuda())
+    monkeypatch.setattr(torch, "randn_like", lambda t, **k: g["noise"].cuda())
+    loss = G.EDMLoss()(m, y, cube, "radar")
+    ref = float(g["loss"])
+    print("EDMLoss", float(loss), "ref", ref)
+    assert abs(float(loss) - ref) < 2e-2 * abs(ref)

@@ -133,3 +133,14 @@ def test_g6_edm_loss(sd_d2):
     y = synth.normal([2, 512, 32], 21)
     loss = O.edm_loss(sd_d2, y, cond, g["rnd_normal"], g["noise"], depth=2)
     assert abs(loss.item() - g["loss"].item()) < 1e-5 * abs(g["loss"].item())
+
+
+def test_g8_radar_autoencoder_encode_and_keys():
+    keys = json.load(open(os.path.join(GOLDEN, "state_dict_keys_radar_ae.json")))["ae_ch64_mult5_n2_d16"]
+    spec = weights.radar_autoencoder_spec(64)
+    assert [[n, list(s)] for n, s in spec] == keys
+    sd = weights.make_state_dict(spec, 0)
+    g = load_golden("g8_radar_autoencoder.npz")
+    cube = synth.radar_cube(2)
+    z = O.radar_encoder(sd, cube.permute(0, 4, 1, 2, 3), prefix="encoder.").permute(0, 2, 3, 4, 1)
+    assert rel_l2(z, g["z"]) < TOL
