@@ -40,13 +40,18 @@ def dist_setup(n_gpus):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = max(torch.cuda.device_count(), 1)
+    dev = local % ndev                      # one rank per GPU; the modulo only matters for 1-GPU rehearsals
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(0)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        backend = os.environ.get("RALD_DIST_BACKEND", "nccl")      # nccl = RCCL over xGMI; gloo for rehearsals
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend=backend)
     return world, rank, local
 
 
@@ -61,7 +66,8 @@ def max_over_ranks(val, world):
     if world == 1:
         return val
     import torch.distributed as dist
-    t = torch.tensor([val], dtype=torch.float64, device="cuda")
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([val], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
