@@ -211,6 +211,7 @@ int Ae::finalize() {
     RALD_CHECK(tmp, "ae: allocation failed");
     RALD_TRY(layernorm_mod(d_lat, tmp, M, d, mix.ng, mix.nb, 0, 1 << 30, 0.f, 1e-5f, nullptr));
     GemmArgs g = gemm_args(tmp, d, mix.w_q, d, q1, I, nullptr, M, I, d);
+    g.alpha = (1.0f / sqrtf((float)cfg.dim_head)) * 1.4426950408889634f;     // q1 carries the softmax scale * log2(e)
     RALD_TRY(gemm_nt(g, EPI_BF16, nullptr));
     RALD_HIP(hipDeviceSynchronize());
     arena.release(tmp);
@@ -291,7 +292,7 @@ int Ae::encode(const float* pc, int B, const float* eps, float* mean_o, float* l
     a1.K = e_k; a1.ldk = I; a1.strideK = (int64_t)Pp * I;
     a1.Vt = e_vt; a1.ldvt = Pp; a1.strideVt = (int64_t)I * Pp;
     a1.O = e_o; a1.ldo = I; a1.strideO = (int64_t)M * I;
-    a1.nq = M; a1.nk = P; a1.k_rows = Pp; a1.heads = cfg.heads; a1.batch = B; a1.scale = 1.0f / sqrtf((float)cfg.dim_head);
+    a1.nq = M; a1.nk = P; a1.k_rows = Pp; a1.heads = cfg.heads; a1.batch = B; a1.scale = 1.0f / sqrtf((float)cfg.dim_head); a1.q_prescaled = 1;
     RALD_TRY(attention_d64(a1, st));
     GemmArgs o1 = gemm_args(e_o, I, mix.w_o, I, e_dq, d, mix.b_o, BM, d, I);
     RALD_TRY(gemm_nt(o1, EPI_F32, st));
@@ -382,6 +383,7 @@ int Ae::decode_latents(const float* z, int B, void* ctx, hipStream_t st) {
         const Layer& l = layers[li];
         // x = self_attn(x) + x   (:413); LN(x) is already in x_h (prologue / previous layer's FF2 epilogue)
         GemmArgs qk = gemm_args(x_h, d, l.w_qk, d, x_qk, 2 * I, nullptr, BM, 2 * I, d);
+        qk.alpha = scale * 1.4426950408889634f; qk.alpha_ncols = I;
         RALD_TRY(gemm_nt(qk, EPI_BF16, st));
         GemmArgs vt = gemm_args(l.w_v, d, x_h, d, x_vt, M, nullptr, I, M, d);
         vt.batch = B; vt.strideB = (int64_t)M * d; vt.strideC = (int64_t)I * M;
@@ -391,7 +393,7 @@ int Ae::decode_latents(const float* z, int B, void* ctx, hipStream_t st) {
         a.K = x_qk + I; a.ldk = 2 * I; a.strideK = (int64_t)M * 2 * I;
         a.Vt = x_vt; a.ldvt = M; a.strideVt = (int64_t)I * M;
         a.O = x_o; a.ldo = I; a.strideO = (int64_t)M * I;
-        a.nq = M; a.nk = M; a.k_rows = M; a.heads = cfg.heads; a.batch = B; a.scale = scale;
+        a.nq = M; a.nk = M; a.k_rows = M; a.heads = cfg.heads; a.batch = B; a.scale = scale; a.q_prescaled = 1;
         RALD_TRY(attention_d64(a, st));
         RALD_TRY(resid_ln(x_o, I, l.w_o, I, l.b_o, I, l.ff.ng, l.ff.nb));             // + the FF's PreNorm
         // x = self_ff(x) + x                                                            (:414)

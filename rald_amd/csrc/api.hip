@@ -153,7 +153,7 @@ int rald_op_gemm_nt(const void* A, int64_t lda, int64_t strideA, const void* B, 
     RALD_CHECK(A && B && C, "rald_op_gemm_nt: null pointer");
     GemmArgs g;
     g.A = (const bf16*)A; g.lda = lda; g.strideA = strideA; g.B = (const bf16*)B; g.ldb = ldb; g.strideB = strideB;
-    g.C = C; g.ldc = ldc; g.strideC = strideC; g.bias = bias; g.M = M; g.N = N; g.K = K; g.batch = batch; g.alpha = alpha; g.ablate = 0;
+    g.C = C; g.ldc = ldc; g.strideC = strideC; g.bias = bias; g.M = M; g.N = N; g.K = K; g.batch = batch; g.alpha = alpha; g.alpha_ncols = 1 << 30; g.ablate = 0;
     if (const char* e = getenv("RALD_GEMM_ABLATE")) g.ablate = atoi(e);
     return gemm_nt(g, epilogue, (hipStream_t)stream);
 }
@@ -169,7 +169,8 @@ int rald_op_attention(const void* Q, int64_t ldq, int64_t strideQ, const void* K
     AttnArgs a;
     a.Q = (const bf16*)Q; a.ldq = ldq; a.strideQ = strideQ; a.K = (const bf16*)K; a.ldk = ldk; a.strideK = strideK;
     a.Vt = (const bf16*)Vt; a.ldvt = ldvt; a.strideVt = strideVt; a.O = (bf16*)O; a.ldo = ldo; a.strideO = strideO;
-    a.nq = nq; a.nk = nk; a.k_rows = k_rows; a.heads = heads; a.batch = batch; a.scale = scale;
+    a.nq = nq; a.nk = nk; a.k_rows = k_rows; a.heads = heads; a.batch = batch; a.scale = scale; a.q_prescaled = 0;
+    if (const char* e = getenv("RALD_ATTN_PRESCALED")) a.q_prescaled = atoi(e);   // timing experiments only
     return attention_d64(a, (hipStream_t)stream);
 }
 int rald_op_gemm_resid_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* x, void* h_bf16,

@@ -19,6 +19,8 @@
 //   * softmax scale and log2(e) ride in the exp2 argument's FMA; masking runs only on a ragged last
 //     tile; the O rescale is skipped (wave-uniformly) when no lane's running max moved.
 //   * O leaves through a wave-private LDS transpose as whole 128-byte rows.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -29,6 +31,7 @@ typedef const __attribute__((address_space(1))) void glb_void;
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+template <bool PRESCALED>
 __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
     constexpr int TILE_BYTES = 64 * 128;                       // 64 rows x 128 B (K: keys x d, Vt: d x keys)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE_BYTES];   // [buf][K | Vt]
@@ -71,12 +74,22 @@ __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
     f32x16 o0, o1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
-    float m = -1e30f, l = 0.f;                                 // m: running max of the RAW scores
-    const float c = a.scale * 1.4426950408889634f;             // exp(scale*s) = exp2(c*s)
+    // Running max m and the exponent scale.  PRESCALED: q already carries scale*log2(e) (folded into
+    // the projection GEMM's epilogue for free), scores are in exp2 units, and -m sits in a 16-register
+    // splat that is the C-INPUT of the first QK^T MFMA: the accumulator comes out as (s - m) and feeds
+    // v_exp_f32 directly - no per-score FMA.  The splat is rewritten only when a max moves (rare).
+    float m = -1e30f, l = 0.f;
+    const float c = PRESCALED ? 1.0f : a.scale * 1.4426950408889634f;
+    f32x16 negm;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) negm[i] = 0.f;
+    (void)negm;
 
     const int ntiles = (a.nk + 63) / 64;
     stage(0, 0);
-    for (int t = 0; t < ntiles; ++t) {
+    // one key tile; FIRST (compile-time) peels the tile whose scores are still absolute
+    auto tile = [&](const int t, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         const int j0 = t * 64;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my pieces of tile t have landed
         __builtin_amdgcn_s_barrier();                          // ... and everyone's; buffer (t+1)&1 is free
@@ -89,8 +102,11 @@ __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
         f32x16 st[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
+            if constexpr (PRESCALED && !FIRST) st[u] = negm;                // accumulator starts at -m
+            else {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) st[u][i] = 0.f;
+                for (int i = 0; i < 16; ++i) st[u][i] = 0.f;
+            }
             const int krow = 32 * u + r;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -98,7 +114,7 @@ __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
                 st[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[u], 0, 0, 0);
             }
         }
-        // st[u][i] = raw score(key j0 + 32u + (i&3) + 8*(i>>2) + 4*hf, query q0 + r)
+        // st[u][i] = score(key j0 + 32u + (i&3) + 8*(i>>2) + 4*hf, query q0 + r)  [PRESCALED: minus m, exp2 units]
         if (j0 + 64 > a.nk) {                                  // ragged last tile only (wave-uniform)
 #pragma unroll
             for (int u = 0; u < 2; ++u)
@@ -112,24 +128,55 @@ __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[1][i]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        if (__any(mx > m)) {                                   // somebody's max moved: rescale what is at the old max
-            const float mn = fmaxf(m, mx);
-            const float alpha = fast_exp2((m - mn) * c);
-            m = mn;
-            l *= alpha;
+        if constexpr (PRESCALED) {
+            // mx is relative to the old max (absolute on the first tile): > 0 means this lane's max moved
+            if (FIRST || __any(mx > 0.f)) {
+                const float delta = FIRST ? mx : fmaxf(mx, 0.f);
+                if constexpr (FIRST) m = mx;
+                else {
+                    const float alpha = fast_exp2(-delta);
+                    m += delta;
+                    l *= alpha;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
-        }
-        const float mc = -m * c;
-        float ps = 0.f;
+                    for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+                }
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+                for (int i = 0; i < 16; ++i) negm[i] = -m;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                st[u][i] = fast_exp2(fmaf(st[u][i], c, mc));
-                ps += st[u][i];
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) st[u][i] -= delta;
             }
-        l += ps;                                               // per-half partial; halves summed at the end
+            f32x2 ps2 = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    st[u][i] = fast_exp2(st[u][i]);
+                    st[u][i + 1] = fast_exp2(st[u][i + 1]);
+                    ps2 += f32x2{st[u][i], st[u][i + 1]};
+                }
+            l += ps2[0] + ps2[1];                              // per-half partial; halves summed at the end
+        } else {
+            if (__any(mx > m)) {                               // somebody's max moved: rescale what is at the old max
+                const float mn = fmaxf(m, mx);
+                const float alpha = fast_exp2((m - mn) * c);
+                m = mn;
+                l *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+            }
+            const float mc = -m * c;
+            float ps = 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    st[u][i] = fast_exp2(fmaf(st[u][i], c, mc));
+                    ps += st[u][i];
+                }
+            l += ps;
+        }
 
         // ---- O^T += V^T.P^T ; element j of the P fragment <-> key 32u + 16s + 8(j>>2) + 4hf + (j&3)
 #pragma unroll
@@ -151,7 +198,9 @@ __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
                     else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o1, 0, 0, 0);
                 }
             }
-    }
+    };
+    tile(0, std::true_type{});
+    for (int t = 1; t < ntiles; ++t) tile(t, std::false_type{});
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
 
@@ -187,7 +236,8 @@ int attention_d64(const AttnArgs& a, hipStream_t st) {
     RALD_CHECK(a.ldvt >= round_up(a.nk, 64), "attention: Vt rows must be padded (finite values) to a multiple of 64 keys");
     RALD_CHECK(((uintptr_t)a.Q % 16 == 0) && ((uintptr_t)a.K % 16 == 0) && ((uintptr_t)a.Vt % 16 == 0) && ((uintptr_t)a.O % 16 == 0), "attention: pointers must be 16-byte aligned");
     dim3 grid(cdiv(a.nq, 128), a.heads, a.batch);
-    hipLaunchKernelGGL(attention_d64_kernel, grid, dim3(256), 0, st, a);
+    if (a.q_prescaled) hipLaunchKernelGGL(attention_d64_kernel<true>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(attention_d64_kernel<false>, grid, dim3(256), 0, st, a);
     RALD_HIP(hipGetLastError());
     return 0;
 }

@@ -358,6 +358,7 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
     const bf16* Kc = (const bf16*)cache;
     const bf16* Vtc = Kc + (size_t)B * T * L * D;
     const float scale = 1.0f / sqrtf((float)cfg.d_head);
+    const float qscale = scale * 1.4426950408889634f;     // softmax scale and log2(e) folded into q by the projection epilogue
 
     // RALD_FUSE_LN=0 falls back to separate LayerNorm launches (A/B and debugging)
     static const bool fuse_ln = !(getenv("RALD_FUSE_LN") && atoi(getenv("RALD_FUSE_LN")) == 0);
@@ -386,6 +387,7 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
         // (norm1(x) is already in ws_h: produced by the previous block's FF2 epilogue / the prologue)
         (void)m1;
         GemmArgs qk = gemm_args(ws_h, D, l.w_qk, D, ws_qk, 2 * D, nullptr, M, 2 * D, D);
+        qk.alpha = qscale; qk.alpha_ncols = D;                                      // q columns only
         RALD_TRY(gemm_nt(qk, EPI_BF16, st));
         GemmArgs vt = gemm_args(l.w_v, D, ws_h, D, ws_vt, NL, nullptr, D, NL, D);   // V^T = Wv . h^T per sample
         vt.batch = B; vt.strideB = (int64_t)NL * D; vt.strideC = (int64_t)D * NL;
@@ -395,18 +397,19 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
         a1.K = ws_qk + D; a1.ldk = 2 * D; a1.strideK = (int64_t)NL * 2 * D;
         a1.Vt = ws_vt; a1.ldvt = NL; a1.strideVt = (int64_t)D * NL;
         a1.O = ws_o; a1.ldo = D; a1.strideO = (int64_t)NL * D;
-        a1.nq = NL; a1.nk = NL; a1.k_rows = NL; a1.heads = cfg.n_heads; a1.batch = B; a1.scale = scale;
+        a1.nq = NL; a1.nk = NL; a1.k_rows = NL; a1.heads = cfg.n_heads; a1.batch = B; a1.scale = scale; a1.q_prescaled = 1;
         RALD_TRY(attention_d64(a1, st));
         RALD_TRY(resid_ln(ws_o, D, l.w_o, D, l.b_o, D, m2));                       // + norm2 for the next sub-block
         // ---- x += attn2(norm2(x, t), context)                                      (:167)
         GemmArgs q2 = gemm_args(ws_h, D, l.w_q2, D, ws_q2, D, nullptr, M, D, D);
+        q2.alpha = qscale;
         RALD_TRY(gemm_nt(q2, EPI_BF16, st));
         AttnArgs a2;
         a2.Q = ws_q2; a2.ldq = D; a2.strideQ = (int64_t)NL * D;
         a2.K = Kc + (size_t)li * D; a2.ldk = (int64_t)L * D; a2.strideK = (int64_t)T * L * D;
         a2.Vt = Vtc + (size_t)li * D * T; a2.ldvt = T; a2.strideVt = (int64_t)L * D * T;
         a2.O = ws_o; a2.ldo = D; a2.strideO = (int64_t)NL * D;
-        a2.nq = NL; a2.nk = T; a2.k_rows = T; a2.heads = cfg.n_heads; a2.batch = B; a2.scale = scale;
+        a2.nq = NL; a2.nk = T; a2.k_rows = T; a2.heads = cfg.n_heads; a2.batch = B; a2.scale = scale; a2.q_prescaled = 1;
         RALD_TRY(attention_d64(a2, st));
         RALD_TRY(resid_ln(ws_o, D, l.w_o2, D, l.b_o2, D, m3));                     // + norm3
         // ---- x += ff(norm3(x, t))                                                   (:168)

@@ -65,14 +65,15 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NT], const GemmAr
                 f32x4 v = acc[i][j];
                 float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (a.bias) b = *reinterpret_cast<const float4*>(a.bias + n);
+                const float al = n < a.alpha_ncols ? a.alpha : 1.0f;
                 if constexpr (EPI == EPI_BF16) {
                     bf16* C = reinterpret_cast<bf16*>(a.C) + (int64_t)bz * a.strideC;
                     *reinterpret_cast<bf16x4*>(C + (int64_t)m * a.ldc + n) =
-                        pack4(a.alpha * v[0] + b.x, a.alpha * v[1] + b.y, a.alpha * v[2] + b.z, a.alpha * v[3] + b.w);
+                        pack4(al * v[0] + b.x, al * v[1] + b.y, al * v[2] + b.z, al * v[3] + b.w);
                 } else if constexpr (EPI == EPI_F32) {
                     float* C = reinterpret_cast<float*>(a.C) + (int64_t)bz * a.strideC;
                     *reinterpret_cast<float4*>(C + (int64_t)m * a.ldc + n) =
-                        make_float4(a.alpha * v[0] + b.x, a.alpha * v[1] + b.y, a.alpha * v[2] + b.z, a.alpha * v[3] + b.w);
+                        make_float4(al * v[0] + b.x, al * v[1] + b.y, al * v[2] + b.z, al * v[3] + b.w);
                 } else {  // EPI_RESID
                     float* C = reinterpret_cast<float*>(a.C) + (int64_t)bz * a.strideC;
                     float4* p = reinterpret_cast<float4*>(C + (int64_t)m * a.ldc + n);
@@ -126,7 +127,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[MT][NT], const Ge
                 float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (a.bias && n < a.N) b = *reinterpret_cast<const float4*>(a.bias + n);
                 const f32x4 v = acc[i][j];
-                const float o0 = a.alpha * v[0] + b.x, o1 = a.alpha * v[1] + b.y, o2 = a.alpha * v[2] + b.z, o3 = a.alpha * v[3] + b.w;
+                const float al = n < a.alpha_ncols ? a.alpha : 1.0f;
+                const float o0 = al * v[0] + b.x, o1 = al * v[1] + b.y, o2 = al * v[2] + b.z, o3 = al * v[3] + b.w;
                 if constexpr (F32OUT) *reinterpret_cast<float4*>(patch + fr * STRIDE + (16 * j + 4 * fq) * 4) = make_float4(o0, o1, o2, o3);
                 else *reinterpret_cast<bf16x4*>(patch + fr * STRIDE + (16 * j + 4 * fq) * 2) = pack4(o0, o1, o2, o3);
             }

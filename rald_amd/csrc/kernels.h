@@ -13,6 +13,7 @@ struct GemmArgs {
     const float* bias;                             // [N] or nullptr
     int M, N, K, batch;
     float alpha;
+    int alpha_ncols;                               // alpha applies to output columns n < alpha_ncols only (others use 1)
     int ablate;                                    // diagnostics only (RALD_GEMM_ABLATE): 1 = no DMA in the loop, 2 = no epilogue
 };
 int gemm_nt(const GemmArgs& a, int epi, hipStream_t st);
@@ -20,7 +21,7 @@ inline GemmArgs gemm_args(const bf16* A, int64_t lda, const bf16* B, int64_t ldb
                           const float* bias, int M, int N, int K) {
     GemmArgs g;
     g.A = A; g.lda = lda; g.strideA = 0; g.B = B; g.ldb = ldb; g.strideB = 0;
-    g.C = C; g.ldc = ldc; g.strideC = 0; g.bias = bias; g.M = M; g.N = N; g.K = K; g.batch = 1; g.alpha = 1.f; g.ablate = 0;
+    g.C = C; g.ldc = ldc; g.strideC = 0; g.bias = bias; g.M = M; g.N = N; g.K = K; g.batch = 1; g.alpha = 1.f; g.alpha_ncols = 1 << 30; g.ablate = 0;
     return g;
 }
 
@@ -58,8 +59,9 @@ struct AttnArgs {
     const bf16* Vt; int64_t ldvt, strideVt;    // Vt[b][h*64+d][j]  (keys contiguous, zero padded to 32)
     bf16* O;        int64_t ldo,  strideO;     // O [b][i][h*64+d]
     int nq, nk, heads, batch;
-    int k_rows;                                // rows allocated per batch in K (>= round_up(nk,32): the tail tile reads them)
-    float scale;
+    int k_rows;                                // rows allocated per batch in K (>= round_up(nk,64): the tail tile reads them)
+    float scale;                               // softmax scale; ignored when q_prescaled
+    int q_prescaled;                           // Q already multiplied by scale*log2(e) (done for free in the producing GEMM's epilogue)
 };
 int attention_d64(const AttnArgs& a, hipStream_t st);
 

@@ -14,6 +14,11 @@ def run(M,N,K,epi,impl,abl,reps=20):
     return s.elapsed_time(e)/reps*1e3
 if __name__ != "__main__": raise SystemExit
 M=16384
+if len(sys.argv) > 1 and sys.argv[1] == "prio":
+    for name,N,K,epi in [("ff1",4096,512,3),("qk",1024,512,0),("ff2",512,2048,2)]:
+        for impl in (1, 3, 5):
+            print(name, "impl%d" % impl, " ".join(f"abl{a}:{run(M,N,K,epi,impl,a):7.1f}us" for a in (0, 32, 0, 32)), flush=True)
+    raise SystemExit
 if len(sys.argv) > 1 and sys.argv[1] == "epi":
     for impl in (1, 5):
         print("ff1 impl%d" % impl, " ".join(f"abl{a}:{run(M,4096,512,3,impl,a):7.1f}us" for a in (0, 8, 16, 24, 2)), flush=True)
