@@ -100,7 +100,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[MT][NT], const Ge
     constexpr int ROWB = OC * (F32OUT ? 4 : 2);                          // bytes per output row
     constexpr int STRIDE = ROWB + 16;
     constexpr int LPR = ROWB / 16;                                       // lanes per row (16 B each)
-    constexpr int RPI = 64 / LPR;                                        // rows per store instruction
+    constexpr int RPI = (64 / LPR) > 16 ? 16 : (64 / LPR);               // rows per store instruction (narrow tiles: lanes >= 16*LPR idle)
     static_assert(ROWB % 16 == 0 && 64 % LPR == 0 && 16 % RPI == 0 && 16 * STRIDE <= 8704, "epilogue tiling");
     const int oc0 = (EPI == EPI_GEGLU) ? nb / 2 : nb;                     // first output column
     const int ncols = (EPI == EPI_GEGLU) ? a.N / 2 : a.N;
@@ -137,6 +137,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[MT][NT], const Ge
 #pragma unroll
         for (int r0 = 0; r0 < 16; r0 += RPI) {
             const int r = r0 + lane / LPR, pc = lane % LPR;
+            if (lane / LPR >= RPI) continue;
             const int m = mb + i * 16 + r;
             const uint4 v = *reinterpret_cast<const uint4*>(patch + r * STRIDE + pc * 16);
             constexpr int EPP = F32OUT ? 4 : 8;                           // elements per 16-byte piece
@@ -463,7 +464,13 @@ int gemm_nt(const GemmArgs& a, int epi, hipStream_t st) {
     int impl = -1;
     if (const char* e = getenv("RALD_GEMM_IMPL")) impl = atoi(e);
     const int64_t wg128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) * a.batch;
-    if (wg128 < 192) return launch_tile<64, 64>(a, epi, st);      // small-M (batch-1) regime
+    if (wg128 < 192) {
+        // small-M (batch-1) regime: too few tiles to hide memory latency behind other workgroups, so put
+        // (up to) the whole K extent in flight at once: 64x64 tiles, 8-stage LDS-DMA ring (128 KB).
+        const int64_t wg64 = (int64_t)cdiv(a.M, 64) * cdiv(a.N, 64) * a.batch;
+        if (impl == 0 || wg64 > 256) return launch_tile<64, 64>(a, epi, st);   // more than one tile per CU: 5 small workgroups/CU hide latency
+        return launch_glds<64, 64, 2, 2, 8>(a, epi, st);
+    }
     if (impl < 0) {
         const int64_t wg256 = (int64_t)(a.M / 256) * (a.N / 256) * a.batch;
         if (a.M % 256 == 0 && a.N % 256 == 0 && wg256 >= 256) return launch_glds<256, 256, 4, 2, 2>(a, epi, st);
