@@ -191,7 +191,7 @@ def main():
                    "weights": "seeded random (rald_amd.weights, seed 0)"},
         "whole_path_tflops": value * GFLOP_PER_NFE / 1e3,
         "heun_steps_per_s": value * 18.0 / 35.0, "samples_per_s_18step": value / 35.0,
-        "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<128,128,GEGLU> (FF1: [B*512,512]x[512,4096], GEGLU epilogue)",
+        "roofline": {"bound": "mfma", "kernel": "rald::gemm_nt_glds_kernel<256,256,4,2,2,EPI_GEGLU> (FF1: [B*512,512]x[512,4096]^T, GEGLU epilogue)",
                      "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
                      "launches_timed": ff1_launches, "avg_launch_us": avg_s * 1e6,
