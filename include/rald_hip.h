@@ -143,6 +143,27 @@ int rald_radar_finalize(rald_radar* h);
 int rald_radar_encode(rald_radar* h, const float* cube, int32_t batch, float* out_z, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Decode post-processing on the device (the host tail of engine_generation.evaluate, :229-243 and
+ * :283-322; utils/utils.py:50-75 inverse_norm_points, :116-142 cal_metrics;
+ * dataset_preprocessor/lidar.py:57-63 polar2cartesian)
+ * ---------------------------------------------------------------------------------------- */
+int64_t rald_post_scratch_bytes(int64_t n_queries);
+/* np.where(logits > threshold) + grid[ind] + inverse_norm_points (+ polar2cartesian if view_cone_mode):
+ * positives are written in ascending query index to out_points [<=Q,3] (out_index optional, may be
+ * NULL), their number to *out_count (device int64).  pc_range6_host = [min0,min1,min2,max0,max1,max2]. */
+int rald_post_occupied_points(const float* logits, const float* queries, int64_t n_queries, const float* pc_range6_host,
+                              int32_t norm_anisotropy, int32_t norm_isotropy, int32_t view_cone_mode, float threshold,
+                              float* out_points, int64_t* out_index, int64_t* out_count, void* scratch, void* stream);
+/* inverse_norm_points (+ polar2cartesian) of a whole array (the ground-truth surface, :290, :317) */
+int rald_post_transform_points(const float* points, int64_t n, const float* pc_range6_host, int32_t norm_anisotropy,
+                               int32_t norm_isotropy, int32_t view_cone_mode, float* out_points, void* stream);
+/* cal_metrics' two sums (exact nearest neighbour, fp64): out_sums2[0] = sum_pred min_gt ||.||,
+ * out_sums2[1] = sum_gt min_pred ||.||;  chamfer = 0.5*out[0]/n_pred + 0.5*out[1]/n_gt */
+int rald_post_chamfer_sums(const float* pred, int64_t n_pred, const float* gt, int64_t n_gt, double* out_sums2, void* stream);
+/* pred = logits >= 0; accuracy[b] = mean(pred == labels); iou[b] = |pred & labels| / |pred | labels| + 1e-5 */
+int rald_post_iou(const float* logits, const float* labels, int32_t batch, int64_t n_queries, float* out_accuracy, float* out_iou, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Kernel-level entry points (what the parity tests and microbenchmarks drive directly)
  * ---------------------------------------------------------------------------------------- */
 /* C[b][m][n] = alpha * sum_k A[b][m][k]*B[b][n][k] (+bias[n]); A,B bf16 (K contiguous).

@@ -1,0 +1,53 @@
+"""CPU ORACLE (test infrastructure only) for the decode post-processing row: a numpy restatement of
+utils/utils.py:50-75 (inverse_norm_points), :116-142 (cal_metrics / chamfer_distance),
+dataset_preprocessor/lidar.py:57-63 (polar2cartesian) and engine_generation.py:229-243, :283-292.
+Pinned against outputs of the reference's own functions (tests/golden/g9_postprocess.npz)."""
+import numpy as np
+
+
+def inverse_norm_points(points, pc_range, norm_anisotropy, norm_isotropy):
+    off = [(pc_range[3 + i] + pc_range[i]) / 2 for i in range(3)]
+    sc = [(pc_range[3 + i] - pc_range[i]) / 2 for i in range(3)]
+    out = np.zeros_like(points)
+    if norm_anisotropy:
+        for i in range(3):
+            out[:, i] = points[:, i] * sc[i] + off[i]
+    if norm_isotropy:
+        out[:, :3] = points[:, :3] * max(sc) + np.array(off)
+    return out
+
+
+def polar2cartesian(points):
+    r, az, el = points[:, 0], -np.deg2rad(points[:, 1]), np.deg2rad(points[:, 2])
+    return np.stack([r * np.cos(el) * np.cos(az), r * np.cos(el) * np.sin(az), r * np.sin(el)], axis=1)
+
+
+def occupied_points(logits, queries, pc_range, aniso, iso, view_cone=True):
+    """np.where(output > 0) -> grid[ind] -> inverse_norm_points -> polar2cartesian (:287-318)."""
+    ind = np.where(logits > 0)[0]
+    pts = inverse_norm_points(queries[ind], pc_range, aniso, iso)
+    return (polar2cartesian(pts) if view_cone else pts), ind
+
+
+def chamfer(y_pred, y_gt, chunk=2048):
+    """Exact nearest-neighbour Chamfer (what cal_metrics gets from its two cKDTrees), brute force in float64."""
+    if len(y_pred) == 0:
+        return np.inf
+    a, b = y_pred.astype(np.float64), y_gt.astype(np.float64)
+
+    def mean_min(p, q):
+        tot = 0.0
+        for i in range(0, len(p), chunk):
+            d = ((p[i:i + chunk, None, :] - q[None, :, :]) ** 2).sum(-1)
+            tot += np.sqrt(d.min(1)).sum()
+        return tot / len(p)
+
+    return 0.5 * mean_min(b, a) + 0.5 * mean_min(a, b)
+
+
+def accuracy_iou(outputs, labels):
+    pred = (outputs >= 0).astype(np.float32)
+    acc = (pred == labels).astype(np.float32).sum(1) / labels.shape[1]
+    inter = (pred * labels).sum(1)
+    union = ((pred + labels) > 0).sum(1)
+    return acc, inter * 1.0 / union + 1e-5

@@ -252,3 +252,40 @@ def golden_radar_autoencoder():
 
 if __name__ == "__main__" and "--g8" in sys.argv:
     pass
+
+
+def golden_postprocess():
+    """G9: the reference's post-processing helpers on seeded synthetic logits / queries / surface
+    (utils/utils.py inverse_norm_points, cal_metrics; dataset_preprocessor/lidar.py polar2cartesian -
+    the latter module needs `easydict` at import, stubbed in memory like the other absent packages)."""
+    sys.path.insert(0, "/root/reference")
+    ed = types.ModuleType("easydict"); ed.EasyDict = dict; sys.modules.setdefault("easydict", ed)
+    import importlib.util
+    import utils.utils as U
+    spec = importlib.util.spec_from_file_location("ref_lidar", "/root/reference/dataset_preprocessor/lidar.py")
+    L = importlib.util.module_from_spec(spec); spec.loader.exec_module(L)
+    pc_range = [0, -90, -20, 15.8, 90, 20]                       # configs/generation/*_eval.yml:52
+    Q = 60000
+    q = synth.queries(1, Q, seed=31)[0].numpy()
+    # occupancy-like logits: positive in a thin shell so ~4 % of the queries are occupied
+    rr = np.linalg.norm(q, axis=1)
+    logits = (0.06 - np.abs(rr - 0.9)).astype(np.float32) * 10 + 0.05 * synth.normal([Q], 32).numpy()
+    surface = synth.point_cloud(1, 10000, seed=33)[0].numpy()
+    ind = np.where(logits > 0)[0]
+    pred_polar = U.inverse_norm_points(q[ind], pc_range, True, False)
+    gt_polar = U.inverse_norm_points(surface, pc_range, True, False)
+    pred, gt = L.polar2cartesian(pred_polar), L.polar2cartesian(gt_polar)
+    cd = U.cal_metrics(y_pred=pred, y_gt=gt)
+    iso = U.inverse_norm_points(q[:1000], pc_range, False, True)
+    labels = (synth.normal([2, 4096], 34).numpy() > 0.3).astype(np.float32)
+    outs = synth.normal([2, 4096], 35).numpy()
+    predb = (outs >= 0).astype(np.float32)
+    acc = (predb == labels).sum(1) / labels.shape[1]
+    iou = (predb * labels).sum(1) / ((predb + labels) > 0).sum(1) + 1e-5
+    save("g9_postprocess.npz", n_pos=np.int64(len(ind)), ind_head=ind[:64], ind_tail=ind[-64:], pred_head=pred[:256], pred_tail=pred[-256:],
+         pred_sum=pred.astype(np.float64).sum(0), gt_head=gt[:256], cd=np.float64(cd), iso_head=iso, acc=acc.astype(np.float32),
+         iou=iou.astype(np.float32))
+
+
+if __name__ == "__main__" and "--g9" in sys.argv:
+    golden_postprocess()
