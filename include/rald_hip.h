@@ -150,12 +150,13 @@ int rald_radar_encode(rald_radar* h, const float* cube, int32_t batch, float* ou
 int64_t rald_post_scratch_bytes(int64_t n_queries);
 /* np.where(logits > threshold) + grid[ind] + inverse_norm_points (+ polar2cartesian if view_cone_mode):
  * positives are written in ascending query index to out_points [<=Q,3] (out_index optional, may be
- * NULL), their number to *out_count (device int64).  pc_range6_host = [min0,min1,min2,max0,max1,max2]. */
-int rald_post_occupied_points(const float* logits, const float* queries, int64_t n_queries, const float* pc_range6_host,
+ * NULL), their number to *out_count (device int64).  pc_range6_host = [min0,min1,min2,max0,max1,max2] as DOUBLES
+ * (the reference's ranges are Python floats; its isotropic branch adds a float64 offset). */
+int rald_post_occupied_points(const float* logits, const float* queries, int64_t n_queries, const double* pc_range6_host,
                               int32_t norm_anisotropy, int32_t norm_isotropy, int32_t view_cone_mode, float threshold,
                               float* out_points, int64_t* out_index, int64_t* out_count, void* scratch, void* stream);
 /* inverse_norm_points (+ polar2cartesian) of a whole array (the ground-truth surface, :290, :317) */
-int rald_post_transform_points(const float* points, int64_t n, const float* pc_range6_host, int32_t norm_anisotropy,
+int rald_post_transform_points(const float* points, int64_t n, const double* pc_range6_host, int32_t norm_anisotropy,
                                int32_t norm_isotropy, int32_t view_cone_mode, float* out_points, void* stream);
 /* cal_metrics' two sums (exact nearest neighbour, fp64): out_sums2[0] = sum_pred min_gt ||.||,
  * out_sums2[1] = sum_gt min_pred ||.||;  chamfer = 0.5*out[0]/n_pred + 0.5*out[1]/n_gt */

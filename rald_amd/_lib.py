@@ -64,9 +64,9 @@ SIGNATURES = {
     "rald_radar_finalize": (c_int, [c_void_p]),
     "rald_radar_encode": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "rald_post_scratch_bytes": (c_i64, [c_i64]),
-    "rald_post_occupied_points": (c_int, [c_void_p, c_void_p, c_i64, c_float_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
+    "rald_post_occupied_points": (c_int, [c_void_p, c_void_p, c_i64, C.POINTER(C.c_double), c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p]),
-    "rald_post_transform_points": (c_int, [c_void_p, c_i64, c_float_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rald_post_transform_points": (c_int, [c_void_p, c_i64, C.POINTER(C.c_double), c_int, c_int, c_int, c_void_p, c_void_p]),
     "rald_post_chamfer_sums": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p]),
     "rald_post_iou": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_void_p, c_void_p, c_void_p]),
     "rald_op_gemm_nt": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p,

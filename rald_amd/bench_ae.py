@@ -49,4 +49,17 @@ def run(batches=(1, 8)) -> dict:
     ms = _time(lambda: h.decode_queries(ctx, q), reps=3, warm=1)
     out["ae_decode_queries_1200k_ms_B1"] = ms
     out["ae_decode_queries_Mq_per_s"] = 1.2e6 / ms / 1e3
+    # decode post-processing on the device: compaction + inverse-norm + polar->cartesian of the
+    # 1.2 M logits, then Chamfer of the positives against a 10 000-point surface
+    from . import postprocess as PP
+    pc_range = [0, -90, -20, 15.8, 90, 20]
+    logits = h.decode_queries(ctx, q)[0]
+    qq = q[0]
+    out["post_occupied_points_1200k_ms"] = _time(lambda: PP.occupied_points(logits, qq, pc_range, True, False, True), reps=5)
+    pts = PP.occupied_points(logits, qq, pc_range, True, False, True)
+    if pts.shape[0] == 0:                      # random weights may put every logit on one side: use a fixed 5 % subset
+        pts = PP.occupied_points(synth.normal([1200000], 5).cuda() - 1.645, qq, pc_range, True, False, True)
+    gt = PP.polar2cartesian(PP.inverse_norm_points(synth.point_cloud(1, 10000, seed=9)[0].cuda(), pc_range, True, False))
+    out["post_chamfer_n_pred"] = int(pts.shape[0])
+    out["post_chamfer_ms"] = _time(lambda: PP.cal_metrics(pts, gt), reps=3)
     return out

@@ -148,13 +148,13 @@ int rald_radar_encode(rald_radar* h, const float* cube, int32_t batch, float* ou
 
 // ---- decode post-processing -----------------------------------------------------
 int64_t rald_post_scratch_bytes(int64_t n_queries) { return (int64_t)post_scratch_ints(n_queries) * 4; }
-int rald_post_occupied_points(const float* logits, const float* queries, int64_t n_queries, const float* pc_range6_host,
+int rald_post_occupied_points(const float* logits, const float* queries, int64_t n_queries, const double* pc_range6_host,
                               int32_t norm_anisotropy, int32_t norm_isotropy, int32_t view_cone_mode, float threshold,
                               float* out_points, int64_t* out_index, int64_t* out_count, void* scratch, void* stream) {
     return post_occupied_points(logits, queries, n_queries, pc_range6_host, norm_anisotropy, norm_isotropy, view_cone_mode, threshold,
                                 out_points, out_index, out_count, (int*)scratch, (hipStream_t)stream);
 }
-int rald_post_transform_points(const float* points, int64_t n, const float* pc_range6_host, int32_t norm_anisotropy,
+int rald_post_transform_points(const float* points, int64_t n, const double* pc_range6_host, int32_t norm_anisotropy,
                                int32_t norm_isotropy, int32_t view_cone_mode, float* out_points, void* stream) {
     return post_transform_points(points, n, pc_range6_host, norm_anisotropy, norm_isotropy, view_cone_mode, out_points, (hipStream_t)stream);
 }

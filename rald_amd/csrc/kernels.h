@@ -94,9 +94,9 @@ int small_k_linear(const float* in, const float* W, const float* bias, float* ou
 
 // ---------------------------------------------------------------- post.hip
 int post_scratch_ints(int64_t Q);
-int post_occupied_points(const float* logits, const float* queries, int64_t Q, const float* pc_range_host, int aniso, int iso,
+int post_occupied_points(const float* logits, const float* queries, int64_t Q, const double* pc_range_host, int aniso, int iso,
                          int view_cone, float thr, float* out_pts, int64_t* out_idx, int64_t* out_count, int* scratch, hipStream_t st);
-int post_transform_points(const float* in, int64_t n, const float* pc_range_host, int aniso, int iso, int view_cone, float* out, hipStream_t st);
+int post_transform_points(const float* in, int64_t n, const double* pc_range_host, int aniso, int iso, int view_cone, float* out, hipStream_t st);
 int post_chamfer_sums(const float* a, int64_t na, const float* b, int64_t nb, double* sums, hipStream_t st);
 int post_iou(const float* logits, const float* labels, int B, int64_t Q, float* acc, float* iou, hipStream_t st);
 

@@ -62,25 +62,26 @@ struct PostXform {
 };
 
 __device__ __forceinline__ void xform_point(const PostXform& t, float px, float py, float pz, float* out) {
+#pragma clang fp contract(off)                               // numpy rounds after every op: no FMA contraction here
     float x = 0.f, y = 0.f, z = 0.f;                         // inverse_norm_points (utils/utils.py:50-75)
     if (t.aniso) {
-        x = __fadd_rn(__fmul_rn(px, t.sx), t.ox);            // two roundings, like numpy (no FMA contraction)
-        y = __fadd_rn(__fmul_rn(py, t.sy), t.oy);
-        z = __fadd_rn(__fmul_rn(pz, t.sz), t.oz);
+        x = px * t.sx + t.ox;                                // two roundings, like numpy
+        y = py * t.sy + t.oy;
+        z = pz * t.sz + t.oz;
     }
     if (t.iso) {
-        x = (float)((double)__fmul_rn(px, t.smax) + t.dox);
-        y = (float)((double)__fmul_rn(py, t.smax) + t.doy);
-        z = (float)((double)__fmul_rn(pz, t.smax) + t.doz);
+        x = (float)((double)(px * t.smax) + t.dox);
+        y = (float)((double)(py * t.smax) + t.doy);
+        z = (float)((double)(pz * t.smax) + t.doz);
     }
     if (t.view_cone) {                                       // polar2cartesian (lidar.py:57-63), fp32 like numpy on float32
         const float d2r = 0.017453292519943295f;
         const float az = -(y * d2r), el = z * d2r;
         const float ce = cosf(el);
         const float r = x;
-        x = __fmul_rn(__fmul_rn(r, ce), cosf(az));
-        y = __fmul_rn(__fmul_rn(r, ce), sinf(az));
-        z = __fmul_rn(r, sinf(el));
+        x = r * ce * cosf(az);
+        y = r * ce * sinf(az);
+        z = r * sinf(el);
     }
     out[0] = x; out[1] = y; out[2] = z;
 }
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void iou_kernel(const float* __restrict__ logi
     }
 }
 
-static PostXform make_xform(const float* pc_range, int aniso, int iso, int view_cone) {
+static PostXform make_xform(const double* pc_range, int aniso, int iso, int view_cone) {
     PostXform t;
     // offsets / scales are Python floats (double) in the reference; the anisotropic branch multiplies a
     // float32 array by them (result float32), the isotropic branch adds a float64 offset array.
@@ -187,7 +188,7 @@ static PostXform make_xform(const float* pc_range, int aniso, int iso, int view_
 
 int post_scratch_ints(int64_t Q) { return (int)((Q + CB - 1) / CB) + 8; }
 
-int post_occupied_points(const float* logits, const float* queries, int64_t Q, const float* pc_range_host, int aniso, int iso,
+int post_occupied_points(const float* logits, const float* queries, int64_t Q, const double* pc_range_host, int aniso, int iso,
                          int view_cone, float thr, float* out_pts, int64_t* out_idx, int64_t* out_count, int* scratch, hipStream_t st) {
     RALD_CHECK(logits && queries && out_pts && out_count && scratch && pc_range_host && Q >= 1, "post_occupied_points: bad argument");
     RALD_CHECK(Q <= (int64_t)1 << 30, "post_occupied_points: too many queries");
@@ -200,7 +201,7 @@ int post_occupied_points(const float* logits, const float* queries, int64_t Q, c
     return 0;
 }
 
-int post_transform_points(const float* in, int64_t n, const float* pc_range_host, int aniso, int iso, int view_cone, float* out, hipStream_t st) {
+int post_transform_points(const float* in, int64_t n, const double* pc_range_host, int aniso, int iso, int view_cone, float* out, hipStream_t st) {
     RALD_CHECK(in && out && pc_range_host && n >= 1, "post_transform_points: bad argument");
     const PostXform t = make_xform(pc_range_host, aniso, iso, view_cone);
     hipLaunchKernelGGL(xform_points_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, n, t, out);

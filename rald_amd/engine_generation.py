@@ -9,6 +9,7 @@ from typing import Callable, Dict, Optional, Sequence
 import torch
 
 from . import distributed as D
+from . import postprocess as PP
 
 
 @torch.no_grad()
@@ -21,6 +22,18 @@ def sample_and_decode(model, vae, radar_cube: torch.Tensor, query_sets: Sequence
     sampled = model.sample(cond=radar_cube, batch_seeds=batch_seeds, cond_type='radar')        # :195
     logits = [vae.decode(sampled, q).squeeze(-1) for q in query_sets]                          # :204, :275, :300
     return {"latents": sampled, "logits": logits, "occupied": [l > 0 for l in logits]}        # :229-232
+
+
+@torch.no_grad()
+def chamfer_of_decode(logits: torch.Tensor, queries: torch.Tensor, surface: torch.Tensor, lidar_pc_range,
+                      norm_anisotropy: bool = True, norm_isotropy: bool = False, view_cone_mode: bool = True) -> float:
+    """engine_generation.py:283-322 for one sample, on the device: positives of `logits` [Q] ->
+    metric (cartesian) coordinates, ground-truth `surface` [P,3] likewise, Chamfer distance."""
+    pred = PP.occupied_points(logits, queries, lidar_pc_range, norm_anisotropy, norm_isotropy, view_cone_mode)
+    gt = PP.inverse_norm_points(surface, lidar_pc_range, norm_anisotropy, norm_isotropy)
+    if view_cone_mode:
+        gt = PP.polar2cartesian(gt)
+    return PP.cal_metrics(pred, gt)
 
 
 @torch.no_grad()

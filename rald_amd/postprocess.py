@@ -19,7 +19,7 @@ from ._lib import check, lib
 def _range(pc_range: Sequence[float]):
     if len(pc_range) != 6:
         raise ValueError("pc_range must have 6 elements [min0,min1,min2,max0,max1,max2]")
-    return (C.c_float * 6)(*[float(v) for v in pc_range])
+    return (C.c_double * 6)(*[float(v) for v in pc_range])      # Python floats in the reference's YAML -> doubles
 
 
 def occupied_points(logits: torch.Tensor, queries: torch.Tensor, lidar_pc_range, norm_anisotropy: bool, norm_isotropy: bool,

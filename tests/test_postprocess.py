@@ -2,7 +2,7 @@
 polar->cartesian, Chamfer distance, accuracy/IoU.  CPU: the numpy oracle against outputs of the
 reference's own helper functions (g9).  GPU: the HIP kernels (through rald_post_*) against the same
 golden and against the oracle on edge cases.  Indices are bit-exact; coordinates agree to fp32
-rounding of cos/sin (<= 2e-6 relative); Chamfer to 1e-6 relative."""
+rounding of cos/sin (<= 8e-6 m at r <= 15.8 m); Chamfer to 1e-6 relative."""
 import numpy as np
 import pytest
 import torch
@@ -51,11 +51,13 @@ def test_hip_postprocess_vs_reference_golden():
     assert np.array_equal(idx[:64], g["ind_head"]) and np.array_equal(idx[-64:], g["ind_tail"])      # order preserved, bit-exact
     assert np.all(np.diff(idx) > 0)
     p = pts.cpu().numpy()
-    assert np.allclose(p[:256], g["pred_head"].numpy(), rtol=2e-6, atol=2e-6)
-    assert np.allclose(p[-256:], g["pred_tail"].numpy(), rtol=2e-6, atol=2e-6)
+    print("max |coord diff| head/tail (m):", np.abs(p[:256] - g["pred_head"].numpy()).max(), np.abs(p[-256:] - g["pred_tail"].numpy()).max())
+    # fp32 cos/sin of the device libm vs numpy's differ by <= ~2 ulp; at r <= 15.8 m that is <= 8e-6 m
+    assert np.allclose(p[:256], g["pred_head"].numpy(), rtol=0, atol=8e-6)
+    assert np.allclose(p[-256:], g["pred_tail"].numpy(), rtol=0, atol=8e-6)
     assert np.allclose(p.astype(np.float64).sum(0), g["pred_sum"].numpy(), rtol=1e-6)
     gt = PP.polar2cartesian(PP.inverse_norm_points(torch.from_numpy(surface).cuda(), PC_RANGE, True, False))
-    assert np.allclose(gt[:256].cpu().numpy(), g["gt_head"].numpy(), rtol=2e-6, atol=2e-6)
+    assert np.allclose(gt[:256].cpu().numpy(), g["gt_head"].numpy(), rtol=0, atol=8e-6)
     cd = PP.cal_metrics(pts, gt)
     print("chamfer", cd, "ref", float(g["cd"]))
     assert abs(cd - float(g["cd"])) < 1e-6 * float(g["cd"])
