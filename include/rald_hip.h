@@ -164,6 +164,14 @@ int rald_post_chamfer_sums(const float* pred, int64_t n_pred, const float* gt, i
 /* pred = logits >= 0; accuracy[b] = mean(pred == labels); iou[b] = |pred & labels| / |pred | labels| + 1e-5 */
 int rald_post_iou(const float* logits, const float* labels, int32_t batch, int64_t n_queries, float* out_accuracy, float* out_iou, void* stream);
 
+/* ColoRadarDataset.process_radar_data (datasets/aligned_coloradar/Coloradar_dataset.py:432-475): raw cube
+ * [B,R,A,E,raw_channels] (intensity dB, doppler, ..., validity mask last; the .bin layout of load_radarcube
+ * :420-430) -> the network's input [B,R,tgt_A,tgt_E,2]: intensity clipped to [0,max] / max, doppler * mask
+ * / max_dopp, bilinear (align_corners=True) upsampling over (A,E). */
+int rald_radar_cube_prepare(const float* raw, int32_t batch, int32_t R, int32_t A, int32_t E, int32_t raw_channels, int32_t tgt_A,
+                            int32_t tgt_E, int32_t norm_intensity, float max_intensity, int32_t norm_dopp, float max_dopp, float* out,
+                            void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Kernel-level entry points (what the parity tests and microbenchmarks drive directly)
  * ---------------------------------------------------------------------------------------- */

@@ -51,3 +51,20 @@ def accuracy_iou(outputs, labels):
     inter = (pred * labels).sum(1)
     union = ((pred + labels) > 0).sum(1)
     return acc, inter * 1.0 / union + 1e-5
+
+
+def process_radar_data(raw, norm_intensity=True, max_intensity=45, norm_dopp=True, max_dopp=2.4958, tgt=(64, 32)):
+    """ColoRadarDataset.process_radar_data (Coloradar_dataset.py:432-475): raw [R,A,E,C] -> [R,tA,tE,2].
+    The up-sampling is the same public torch call the reference makes (F.interpolate bilinear, align_corners=True)."""
+    import torch
+    import torch.nn.functional as F
+    raw = np.array(raw, dtype=np.float32, copy=True)
+    out = np.zeros(raw.shape[:3] + (2,), dtype=np.float32)
+    if norm_intensity:
+        out[..., 0] = np.clip(raw[..., 0], 0, max_intensity) / max_intensity
+    out[..., 1] = raw[..., 1] * raw[..., -1]
+    if norm_dopp:
+        out[..., 1] = out[..., 1] / max_dopp
+    chans = [F.interpolate(torch.from_numpy(out[..., c]).unsqueeze(0), size=tgt, mode="bilinear", align_corners=True).squeeze(0).numpy()
+             for c in range(2)]
+    return np.stack(chans, axis=-1)

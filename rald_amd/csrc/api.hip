@@ -165,6 +165,13 @@ int rald_post_iou(const float* logits, const float* labels, int32_t batch, int64
     return post_iou(logits, labels, batch, n_queries, out_accuracy, out_iou, (hipStream_t)stream);
 }
 
+int rald_radar_cube_prepare(const float* raw, int32_t batch, int32_t R, int32_t A, int32_t E, int32_t raw_channels, int32_t tgt_A,
+                            int32_t tgt_E, int32_t norm_intensity, float max_intensity, int32_t norm_dopp, float max_dopp, float* out,
+                            void* stream) {
+    return radar_cube_prepare(raw, batch, R, A, E, raw_channels, tgt_A, tgt_E, norm_intensity, max_intensity, norm_dopp, max_dopp, out,
+                              (hipStream_t)stream);
+}
+
 // ---- kernel-level entry points -----------------------------------------------------------------
 int rald_op_gemm_nt(const void* A, int64_t lda, int64_t strideA, const void* B, int64_t ldb, int64_t strideB,
                     void* C, int64_t ldc, int64_t strideC, const float* bias, int32_t M, int32_t N, int32_t K,

@@ -99,5 +99,7 @@ int post_occupied_points(const float* logits, const float* queries, int64_t Q, c
 int post_transform_points(const float* in, int64_t n, const double* pc_range_host, int aniso, int iso, int view_cone, float* out, hipStream_t st);
 int post_chamfer_sums(const float* a, int64_t na, const float* b, int64_t nb, double* sums, hipStream_t st);
 int post_iou(const float* logits, const float* labels, int B, int64_t Q, float* acc, float* iou, hipStream_t st);
+int radar_cube_prepare(const float* raw, int B, int R, int A, int E, int Craw, int tA, int tE, int norm_i, float max_i, int norm_d,
+                       float max_d, float* out, hipStream_t st);
 
 }  // namespace rald

@@ -227,3 +227,54 @@ int post_iou(const float* logits, const float* labels, int B, int64_t Q, float* 
 }
 
 }  // namespace rald
+
+namespace rald {
+
+// ---- radar cube preprocessing (datasets/aligned_coloradar/Coloradar_dataset.py:432-475, process_radar_data):
+// raw [B][R][A][E][Craw] (intensity dB, doppler, ..., validity mask LAST) -> out [B][R][tA][tE][2]
+//   ch0 = clip(intensity, 0, max_i) / max_i ; ch1 = doppler * mask (/ max_dopp), then bilinear upsampling
+//   over (A, E) with align_corners=True (F.interpolate, :465-470).  One thread per output element pair.
+__global__ void radar_cube_prepare_kernel(const float* __restrict__ raw, float* __restrict__ out, int64_t n_out, int A, int E, int Craw,
+                                          int tA, int tE, int norm_i, float max_i, int norm_d, float max_d) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    const int te = (int)(i % tE);
+    const int ta = (int)((i / tE) % tA);
+    const int64_t br = i / ((int64_t)tE * tA);                       // b*R + r
+    // source coordinates, align_corners=True: src = dst * (in-1)/(out-1)   (torch upsample_bilinear2d)
+    const float ra = tA > 1 ? (float)(A - 1) / (float)(tA - 1) : 0.f;
+    const float re = tE > 1 ? (float)(E - 1) / (float)(tE - 1) : 0.f;
+    const float a1r = ra * ta, e1r = re * te;
+    const int a1 = (int)a1r, e1 = (int)e1r;
+    const int a1p = a1 < A - 1 ? 1 : 0, e1p = e1 < E - 1 ? 1 : 0;
+    const float a1l = a1r - a1, a0l = 1.f - a1l, e1l = e1r - e1, e0l = 1.f - e1l;
+    float v[2][2][2];                                                // [da][de][channel]
+#pragma unroll
+    for (int da = 0; da < 2; ++da)
+#pragma unroll
+        for (int de = 0; de < 2; ++de) {
+            const float* p = raw + ((br * A + (a1 + da * a1p)) * E + (e1 + de * e1p)) * Craw;
+            float in = 0.f;
+            if (norm_i) in = fminf(fmaxf(p[0], 0.f), max_i) / max_i;
+            float dp = p[1] * p[Craw - 1];
+            if (norm_d) dp = dp / max_d;
+            v[da][de][0] = in; v[da][de][1] = dp;
+        }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+        out[i * 2 + c] = a0l * (e0l * v[0][0][c] + e1l * v[0][1][c]) + a1l * (e0l * v[1][0][c] + e1l * v[1][1][c]);
+}
+
+int radar_cube_prepare(const float* raw, int B, int R, int A, int E, int Craw, int tA, int tE, int norm_i, float max_i, int norm_d,
+                       float max_d, float* out, hipStream_t st) {
+    RALD_CHECK(raw && out && B >= 1 && R >= 1 && A >= 1 && E >= 1 && Craw >= 3 && tA >= 1 && tE >= 1, "radar_cube_prepare: bad argument");
+    RALD_CHECK(max_i > 0.f && max_d > 0.f, "radar_cube_prepare: normalisation constants must be positive");
+    const int64_t n_out = (int64_t)B * R * tA * tE;
+    hipLaunchKernelGGL(radar_cube_prepare_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, raw, out, n_out, A, E, Craw, tA,
+                       tE, norm_i, max_i, norm_d, max_d);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace rald

@@ -289,3 +289,30 @@ def golden_postprocess():
 
 if __name__ == "__main__" and "--g9" in sys.argv:
     golden_postprocess()
+
+
+def golden_radar_cube():
+    """G10: ColoRadarDataset.process_radar_data (Coloradar_dataset.py:432-475) on a seeded raw cube
+    [128,8,2,3]; the dataset module imports once `easydict` is stubbed in memory."""
+    sys.path.insert(0, "/root/reference")
+
+    class ED(dict):
+        __getattr__ = dict.__getitem__
+    ed = types.ModuleType("easydict"); ed.EasyDict = ED; sys.modules["easydict"] = ed
+    from datasets.aligned_coloradar.Coloradar_dataset import ColoRadarDataset
+    cfg = ED(radar=ED(input_r_dim=128, input_a_dim=8, input_e_dim=2, upsample=True, tgt_r_dim=128, tgt_a_dim=64, tgt_e_dim=32,
+                      norm_intensity=True, max_intensity=45, norm_dopp=True, max_dopp=2.4958))
+    fake_self = types.SimpleNamespace(config=cfg)
+    g = torch.Generator("cpu").manual_seed(41)
+    raw = torch.empty(128, 8, 2, 3)
+    raw[..., 0] = torch.rand(128, 8, 2, generator=g) * 70 - 10          # dB, some below 0 and above 45
+    raw[..., 1] = torch.randn(128, 8, 2, generator=g) * 1.5             # doppler m/s
+    raw[..., 2] = (torch.rand(128, 8, 2, generator=g) > 0.3).float()    # validity mask
+    out = ColoRadarDataset.process_radar_data(fake_self, raw.numpy().copy())
+    # the full output is 2 MB: keep every 4th range bin plus whole-tensor checksums
+    save("g10_radar_cube.npz", raw=raw, out_r4=out[::4], out_sum=np.float64(out.astype(np.float64).sum()),
+         out_abs_sum=np.float64(np.abs(out).astype(np.float64).sum()))
+
+
+if __name__ == "__main__" and "--g10" in sys.argv:
+    golden_radar_cube()
