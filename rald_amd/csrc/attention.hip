@@ -19,6 +19,7 @@
 //   * softmax scale and log2(e) ride in the exp2 argument's FMA; masking runs only on a ragged last
 //     tile; the O rescale is skipped (wave-uniformly) when no lane's running max moved.
 //   * O leaves through a wave-private LDS transpose as whole 128-byte rows.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
         }
     }
 }
+
 
 int attention_d64(const AttnArgs& a, hipStream_t st) {
     RALD_CHECK(a.nq > 0 && a.nk > 0 && a.heads > 0 && a.batch > 0, "attention: empty problem");
