@@ -345,42 +345,77 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_glds_kernel(GemmArgs a) 
 
     const int nk = a.K / BK;
     const int fr = lane & 15, fq = lane >> 4;
-#pragma unroll
-    for (int s = 0; s < NSTAGE - 1; ++s)
-        if (s < nk) stage(s, s);
-    for (int kt = 0; kt < nk; ++kt) {
-        // tile kt must have landed: allow the NSTAGE-2 younger tiles to stay in flight
-        if (kt + NSTAGE - 2 < nk) {
-            if constexpr (NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * (CA + CB)) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // everyone's pieces of tile kt are in LDS; buffer (kt-1)%NSTAGE is free
-        asm volatile("" ::: "memory");
-        if (kt + NSTAGE - 1 < nk && !(a.ablate & 1)) stage(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);
-        const bf16x8* sA = reinterpret_cast<const bf16x8*>(smem + (kt % NSTAGE) * STAGE_BYTES);
+    // fragment reads of one 32-deep k sub-step (kk) of the tile in LDS buffer `buf`
+    auto read_frags = [&](int buf, int kk, bf16x8 (&fa)[MT], bf16x8 (&fb)[NT]) {
+        const bf16x8* sA = reinterpret_cast<const bf16x8*>(smem + buf * STAGE_BYTES);
         const bf16x8* sB = sA + BM * 8;
+        const int chunk = kk * 4 + fq;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 fa[MT], fb[NT];
-            const int chunk = kk * 4 + fq;
+        for (int i = 0; i < MT; ++i) {
+            const int r = wm * (BM / WM) + i * 16 + fr;
+            fa[i] = sA[r * 8 + (chunk ^ (r & 7))];
+        }
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int r = wm * (BM / WM) + i * 16 + fr;
-                fa[i] = sA[r * 8 + (chunk ^ (r & 7))];
+        for (int j = 0; j < NT; ++j) {
+            const int r = wn * (BN / WN) + j * 16 + fr;
+            fb[j] = sB[r * 8 + (chunk ^ (r & 7))];
+        }
+    };
+    auto mfma_all = [&](const bf16x8 (&fa)[MT], const bf16x8 (&fb)[NT]) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    };
+    if constexpr (NSTAGE == 2) {
+        // Software-pipelined main loop: the fragment registers are double-buffered so that the LDS reads
+        // of the NEXT 32-deep sub-step are in flight while the MFMAs of the current one issue (the
+        // compiler's own schedule was read-burst -> lgkmcnt(0) -> MFMA-burst, four exposed LDS
+        // latencies per tile).  The tile hand-over (DMA wait + barrier + next DMA) sits between the two
+        // MFMA bursts of an iteration, so neither burst waits on LDS.
+        bf16x8 fa0[MT], fb0[NT], fa1[MT], fb1[NT];
+        stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (nk > 1 && !(a.ablate & 1)) stage(1, 1);
+        read_frags(0, 0, fa0, fb0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            read_frags(cur, 1, fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_all(fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tile kt+1 landed; my reads of tile kt are done
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (kt + 2 < nk && !(a.ablate & 1)) stage(kt + 2, cur);      // buffer `cur` is free now
+                read_frags(cur ^ 1, 0, fa0, fb0);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            mfma_all(fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int r = wn * (BN / WN) + j * 16 + fr;
-                fb[j] = sB[r * 8 + (chunk ^ (r & 7))];
+        for (int s = 0; s < NSTAGE - 1; ++s)
+            if (s < nk) stage(s, s);
+        for (int kt = 0; kt < nk; ++kt) {
+            // tile kt must have landed: allow the NSTAGE-2 younger tiles to stay in flight
+            if (kt + NSTAGE - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * (CA + CB)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // everyone's pieces of tile kt are in LDS; buffer (kt-1)%NSTAGE is free
+            asm volatile("" ::: "memory");
+            if (kt + NSTAGE - 1 < nk && !(a.ablate & 1)) stage(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 fa[MT], fb[NT];
+                read_frags(kt % NSTAGE, kk, fa, fb);
+                mfma_all(fa, fb);
             }
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
     }
     if (a.ablate & 2) {                       // diagnostics: keep the accumulators live, store (almost) nothing
