@@ -164,6 +164,36 @@ int rald_post_chamfer_sums(const float* pred, int64_t n_pred, const float* gt, i
 /* pred = logits >= 0; accuracy[b] = mean(pred == labels); iou[b] = |pred & labels| / |pred | labels| + 1e-5 */
 int rald_post_iou(const float* logits, const float* labels, int32_t batch, int64_t n_queries, float* out_accuracy, float* out_iou, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Query generation + refine on the device (the host numpy code between model.sample and vae.decode in
+ * engine_generation.evaluate, :250-300).  Random draws are caller-supplied DEVICE arrays so that the
+ * host mirror can replay numpy's global-RNG stream (bit-identical queries) or use a device generator.
+ * ---------------------------------------------------------------------------------------- */
+/* generate_query_points (utils/utils.py:147-175): u3n = [3,n] float64 uniforms in numpy's draw order
+ * (all x, then all y, then all z); out[i,a] = float32(lo_a + (hi_a - lo_a) * u[a,i]), box = [-1,1]^3
+ * (anisotropic) or +-scale_a/max_scale (isotropic). */
+int rald_query_uniform(const double* u3n, int64_t n, const double* pc_range6_host, int32_t norm_anisotropy, int32_t norm_isotropy,
+                       float* out_queries, void* stream);
+/* the use_cart_query branch (engine_generation.py:251-256): uniform in the cartesian box ->
+ * inverse_norm_points(pc_range_cart) -> cartesian2polar (dataset_preprocessor/lidar.py:49-55) ->
+ * norm_points(pc_range) -> remove_points_outside_fov (utils/utils.py:106-112), float64 throughout,
+ * float32 on output; survivors keep their order, *out_count (device int64) = their number.
+ * scratch: rald_post_scratch_bytes(n). */
+int rald_query_uniform_cart(const double* u3n, int64_t n, const double* pc_range_cart6_host, const double* pc_range6_host,
+                            int32_t norm_anisotropy, int32_t norm_isotropy, float* out_queries, int64_t* out_count, void* scratch,
+                            void* stream);
+/* norm_points (utils/utils.py:77-104) of a float32 array */
+int rald_query_norm_points(const float* points, int64_t n, const double* pc_range6_host, int32_t norm_anisotropy, int32_t norm_isotropy,
+                           float* out_points, void* stream);
+/* aug_query_helper (datasets/utils/query_helper.py:3-42) [+ norm_points when normalise != 0, as
+ * engine_generation.py:292-297 does]: out [aug_num,3] = the first min(n_helper, aug_num) helper points, then
+ * for g < aug_num - n_helper: clip(helper[sel_index[g]] + (2*u_bias[g,:]-1) * voxel_size * aug_scales[g]).
+ * sel_index / aug_scales: int64 [aug_num - n_helper]; u_bias: float64 [aug_num - n_helper, 3] (may be NULL when
+ * n_helper >= aug_num). */
+int rald_query_refine(const float* helper_points, int64_t n_helper, int64_t aug_num, const int64_t* sel_index, const int64_t* aug_scales,
+                      const double* u_bias, const double* pc_range6_host, const double* voxel_size3_host, int32_t norm_anisotropy,
+                      int32_t norm_isotropy, int32_t normalise, float* out_points, void* stream);
+
 /* ColoRadarDataset.process_radar_data (datasets/aligned_coloradar/Coloradar_dataset.py:432-475): raw cube
  * [B,R,A,E,raw_channels] (intensity dB, doppler, ..., validity mask last; the .bin layout of load_radarcube
  * :420-430) -> the network's input [B,R,tgt_A,tgt_E,2]: intensity clipped to [0,max] / max, doppler * mask

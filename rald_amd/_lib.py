@@ -69,6 +69,11 @@ SIGNATURES = {
     "rald_post_transform_points": (c_int, [c_void_p, c_i64, C.POINTER(C.c_double), c_int, c_int, c_int, c_void_p, c_void_p]),
     "rald_post_chamfer_sums": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p]),
     "rald_post_iou": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_void_p, c_void_p, c_void_p]),
+    "rald_query_uniform": (c_int, [c_void_p, c_i64, C.POINTER(C.c_double), c_int, c_int, c_void_p, c_void_p]),
+    "rald_query_uniform_cart": (c_int, [c_void_p, c_i64, C.POINTER(C.c_double), C.POINTER(C.c_double), c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rald_query_norm_points": (c_int, [c_void_p, c_i64, C.POINTER(C.c_double), c_int, c_int, c_void_p, c_void_p]),
+    "rald_query_refine": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), c_int, c_int, c_int,
+                                  c_void_p, c_void_p]),
     "rald_radar_cube_prepare": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_float, c_void_p,
                                         c_void_p]),
     "rald_op_gemm_nt": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p,

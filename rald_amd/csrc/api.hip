@@ -172,6 +172,33 @@ int rald_radar_cube_prepare(const float* raw, int32_t batch, int32_t R, int32_t 
                               (hipStream_t)stream);
 }
 
+// ---- query generation + refine --------------------------------------------------
+int rald_query_uniform(const double* u3n, int64_t n, const double* pc_range6_host, int32_t norm_anisotropy, int32_t norm_isotropy,
+                       float* out_queries, void* stream) {
+    RALD_CHECK(pc_range6_host && (n == 0 || (u3n && out_queries)), "rald_query_uniform: null argument");
+    return query_uniform(u3n, n, pc_range6_host, norm_anisotropy, norm_isotropy, out_queries, (hipStream_t)stream);
+}
+int rald_query_uniform_cart(const double* u3n, int64_t n, const double* pc_range_cart6_host, const double* pc_range6_host,
+                            int32_t norm_anisotropy, int32_t norm_isotropy, float* out_queries, int64_t* out_count, void* scratch,
+                            void* stream) {
+    RALD_CHECK(pc_range_cart6_host && pc_range6_host && out_count && (n == 0 || (u3n && out_queries && scratch)),
+               "rald_query_uniform_cart: null argument");
+    return query_uniform_cart(u3n, n, pc_range_cart6_host, pc_range6_host, norm_anisotropy, norm_isotropy, out_queries, out_count,
+                              (int*)scratch, (hipStream_t)stream);
+}
+int rald_query_norm_points(const float* points, int64_t n, const double* pc_range6_host, int32_t norm_anisotropy, int32_t norm_isotropy,
+                           float* out_points, void* stream) {
+    RALD_CHECK(pc_range6_host && (n == 0 || (points && out_points)), "rald_query_norm_points: null argument");
+    return query_norm_points(points, n, pc_range6_host, norm_anisotropy, norm_isotropy, out_points, (hipStream_t)stream);
+}
+int rald_query_refine(const float* helper_points, int64_t n_helper, int64_t aug_num, const int64_t* sel_index, const int64_t* aug_scales,
+                      const double* u_bias, const double* pc_range6_host, const double* voxel_size3_host, int32_t norm_anisotropy,
+                      int32_t norm_isotropy, int32_t normalise, float* out_points, void* stream) {
+    RALD_CHECK(pc_range6_host && voxel_size3_host && (aug_num == 0 || (helper_points && out_points)), "rald_query_refine: null argument");
+    return query_refine(helper_points, n_helper, aug_num, sel_index, aug_scales, u_bias, pc_range6_host, voxel_size3_host, norm_anisotropy,
+                        norm_isotropy, normalise, out_points, (hipStream_t)stream);
+}
+
 // ---- kernel-level entry points -----------------------------------------------------------------
 int rald_op_gemm_nt(const void* A, int64_t lda, int64_t strideA, const void* B, int64_t ldb, int64_t strideB,
                     void* C, int64_t ldc, int64_t strideC, const float* bias, int32_t M, int32_t N, int32_t K,

@@ -94,6 +94,7 @@ int small_k_linear(const float* in, const float* W, const float* bias, float* ou
 
 // ---------------------------------------------------------------- post.hip
 int post_scratch_ints(int64_t Q);
+void post_scan_counts(int* counts, int nblocks, int64_t* total, hipStream_t st);   // exclusive scan of per-block counts
 int post_occupied_points(const float* logits, const float* queries, int64_t Q, const double* pc_range_host, int aniso, int iso,
                          int view_cone, float thr, float* out_pts, int64_t* out_idx, int64_t* out_count, int* scratch, hipStream_t st);
 int post_transform_points(const float* in, int64_t n, const double* pc_range_host, int aniso, int iso, int view_cone, float* out, hipStream_t st);
@@ -101,5 +102,13 @@ int post_chamfer_sums(const float* a, int64_t na, const float* b, int64_t nb, do
 int post_iou(const float* logits, const float* labels, int B, int64_t Q, float* acc, float* iou, hipStream_t st);
 int radar_cube_prepare(const float* raw, int B, int R, int A, int E, int Craw, int tA, int tE, int norm_i, float max_i, int norm_d,
                        float max_d, float* out, hipStream_t st);
+
+// ---------------------------------------------------------------- query.hip
+int query_uniform(const double* u, int64_t n, const double* pc_range, int aniso, int iso, float* out, hipStream_t st);
+int query_uniform_cart(const double* u, int64_t n, const double* range_cart, const double* range_polar, int aniso, int iso, float* out,
+                       int64_t* out_count, int* scratch, hipStream_t st);
+int query_norm_points(const float* in, int64_t n, const double* pc_range, int aniso, int iso, float* out, hipStream_t st);
+int query_refine(const float* pred, int64_t n_pred, int64_t aug_num, const int64_t* sel, const int64_t* scales, const double* u,
+                 const double* pc_range, const double* voxel, int aniso, int iso, int normalise, float* out, hipStream_t st);
 
 }  // namespace rald

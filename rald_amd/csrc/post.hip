@@ -186,6 +186,10 @@ static PostXform make_xform(const double* pc_range, int aniso, int iso, int view
     return t;
 }
 
+void post_scan_counts(int* counts, int nblocks, int64_t* total, hipStream_t st) {
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, st, counts, nblocks, total);
+}
+
 int post_scratch_ints(int64_t Q) { return (int)((Q + CB - 1) / CB) + 8; }
 
 int post_occupied_points(const float* logits, const float* queries, int64_t Q, const double* pc_range_host, int aniso, int iso,

@@ -1,7 +1,8 @@
 """The ~15 lines of the reference's generation engine that call the hot path
 (engine_generation.py:183-232, :274-300), restated as a batch-sharded driver: radar cube ->
-EDMPrecond.sample -> vae.decode on query sets -> occupancy = logits > 0.  Data loading, PLY
-writing and Chamfer metrics are out of scope."""
+EDMPrecond.sample -> vae.decode on query sets -> occupancy = logits > 0, plus the per-frame
+inference tail (:250-322: query generation, helper points, refine pass, Chamfer) kept on the device.
+Data loading and PLY writing are out of scope."""
 from __future__ import annotations
 
 from typing import Callable, Dict, Optional, Sequence
@@ -10,6 +11,7 @@ import torch
 
 from . import distributed as D
 from . import postprocess as PP
+from . import query_points as QP
 
 
 @torch.no_grad()
@@ -34,6 +36,49 @@ def chamfer_of_decode(logits: torch.Tensor, queries: torch.Tensor, surface: torc
     if view_cone_mode:
         gt = PP.polar2cartesian(gt)
     return PP.cal_metrics(pred, gt)
+
+
+def _get(ns, name, default=None):
+    return ns.get(name, default) if hasattr(ns, "get") else getattr(ns, name, default)
+
+
+@torch.no_grad()
+def infer_point_cloud(vae, sampled_tokens: torch.Tensor, args, helper_points: Optional[torch.Tensor] = None,
+                      surface: Optional[torch.Tensor] = None, rng: Optional[torch.Generator] = None) -> Dict[str, object]:
+    """engine_generation.py:250-322 for ONE sample (the reference asserts batch 1 when helper points are
+    used), everything between the sampler and the metric on the device:
+    uniform (or cartesian-box) queries [+ helper points] -> vae.decode -> positives -> un-normalised polar
+    points -> [refine: jittered copies -> normalise -> decode -> positives] -> cartesian if view_cone_mode
+    -> Chamfer distance against `surface` (normalised ground truth [P,3]) unless skip_eval_metric.
+    `rng=None` consumes numpy's global RNG in the reference's order; a device generator avoids host draws.
+    Returns {'pred': [n,3] metric coordinates, 'cd': float or None, 'n_queries': int}."""
+    if sampled_tokens.shape[0] != 1:
+        raise AssertionError("Batch size should be 1 when using query helper points")          # :265
+    lidar, inf = args.dataset.lidar, args.eval.inference
+    aniso, iso = lidar.norm_anisotropy, lidar.norm_isotropy
+    dev = sampled_tokens.device
+    if _get(args.eval, "use_cart_query", False):
+        grid = QP.generate_cart_query_points(args, device=dev, rng=rng)                        # :251-256
+    else:
+        grid = QP.generate_query_points(args, device=dev, rng=rng)                             # :258
+    if _get(inf, "query_helper", False) and helper_points is not None:
+        grid = torch.cat((grid, helper_points.to(dev, torch.float32).reshape(-1, 3)), dim=0)    # :264-271
+    output = vae.decode(sampled_tokens, grid[None]).squeeze(-1)[0]                              # :275
+    pred = PP.occupied_points(output, grid, lidar.pc_range, aniso, iso, view_cone_mode=False)   # :283-289
+    n_queries = grid.shape[0]
+    if _get(inf, "refine_query", False):
+        refined = QP.refine_queries(pred, args, rng=rng)                                        # :292-297
+        out_r = vae.decode(sampled_tokens, refined[None]).squeeze(-1)[0]                        # :300
+        pred = PP.occupied_points(out_r, refined, lidar.pc_range, aniso, iso, view_cone_mode=False)   # :304-310
+        n_queries += refined.shape[0]
+    view_cone = bool(_get(lidar, "view_cone_mode", False))
+    if view_cone:
+        pred = PP.polar2cartesian(pred)                                                         # :313-315
+    cd = None
+    if surface is not None and not _get(args.eval, "skip_eval_metric", False):
+        gt = PP.inverse_norm_points(surface.to(dev), lidar.pc_range, aniso, iso)                 # :290
+        cd = PP.cal_metrics(pred, PP.polar2cartesian(gt) if view_cone else gt)                   # :320
+    return {"pred": pred, "cd": cd, "n_queries": n_queries}
 
 
 @torch.no_grad()

@@ -229,11 +229,16 @@ def main():
             rnd = torch.randn([2, 1, 1])
             noise = torch.randn_like(y)
             save("g6_edmloss.npz", loss=loss, rnd_normal=rnd, noise=noise)
+    if want("g8"):
+        golden_radar_autoencoder()
+    if want("g9"):
+        golden_postprocess()
+    if want("g10"):
+        golden_radar_cube()
+    if want("g11"):
+        golden_queries()
     print(f"done in {time.time() - t00:.0f}s")
 
-
-if __name__ == "__main__":
-    main()
 
 
 def golden_radar_autoencoder():
@@ -249,9 +254,6 @@ def golden_radar_autoencoder():
         z = m._encode(synth.radar_cube(2))
     save("g8_radar_autoencoder.npz", z=z)
 
-
-if __name__ == "__main__" and "--g8" in sys.argv:
-    pass
 
 
 def golden_postprocess():
@@ -287,9 +289,6 @@ def golden_postprocess():
          iou=iou.astype(np.float32))
 
 
-if __name__ == "__main__" and "--g9" in sys.argv:
-    golden_postprocess()
-
 
 def golden_radar_cube():
     """G10: ColoRadarDataset.process_radar_data (Coloradar_dataset.py:432-475) on a seeded raw cube
@@ -314,5 +313,58 @@ def golden_radar_cube():
          out_abs_sum=np.float64(np.abs(out).astype(np.float64).sum()))
 
 
-if __name__ == "__main__" and "--g10" in sys.argv:
-    golden_radar_cube()
+
+def golden_queries():
+    """G11: the reference's query generation / refine helpers under np.random.seed (utils/utils.py
+    generate_query_points, norm_points, remove_points_outside_fov; datasets/utils/query_helper.py
+    aug_query_helper; dataset_preprocessor/lidar.py cartesian2polar; the use_cart_query chain is
+    engine_generation.py:251-256 restated with the reference's own functions)."""
+    sys.path.insert(0, "/root/reference")
+
+    class ED(dict):
+        __getattr__ = dict.__getitem__
+    ed = types.ModuleType("easydict"); ed.EasyDict = ED; sys.modules.setdefault("easydict", ed)
+    import importlib.util
+    import utils.utils as U
+
+    def by_path(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+        return m
+    L = by_path("ref_lidar", "/root/reference/dataset_preprocessor/lidar.py")
+    QH = by_path("ref_query_helper", "/root/reference/datasets/utils/query_helper.py")
+    pc_range = [0, -90, -20, 15.8, 90, 20]                       # configs/generation/*_eval.yml:52
+    pc_range_cart = [0, -15.8, -5.4, 15.8, 15.8, 5.4]            # :46 (commented alternative of the shipped file)
+    voxel = [0.05, 0.25, 0.5]                                    # :54
+    out = {}
+    for tag, aniso, iso in (("aniso", True, False), ("iso", False, True)):
+        args = ED(eval=ED(inference=ED(num_query_points=20000)),
+                  dataset=ED(lidar=ED(pc_range=pc_range, pc_range_cart=pc_range_cart, norm_anisotropy=aniso, norm_isotropy=iso)))
+        np.random.seed(101)
+        g = U.generate_query_points(args).astype("float32")
+        out[f"uniform_{tag}_head"] = g[:1024]
+        out[f"uniform_{tag}_sum"] = g.astype(np.float64).sum(0)
+        np.random.seed(102)
+        gc = U.generate_query_points(args, coordinate_type="cart")
+        gc = U.inverse_norm_points(gc, pc_range_cart, aniso, iso)
+        gp = L.cartesian2polar(gc)
+        gp = U.norm_points(gp, pc_range, aniso, iso)
+        gp = U.remove_points_outside_fov(gp).astype("float32")
+        out[f"cart_{tag}_n"] = np.int64(len(gp))
+        out[f"cart_{tag}_head"] = gp[:1024]
+        out[f"cart_{tag}_tail"] = gp[-256:]
+        out[f"cart_{tag}_sum"] = gp.astype(np.float64).sum(0)
+        # refine: helper points = un-normalised polar positives, as engine_generation.py:288-297
+        helper = U.inverse_norm_points(synth.queries(1, 2000, seed=51)[0].numpy(), pc_range, True, False)
+        np.random.seed(103)
+        ref = QH.aug_query_helper(helper, 5000, pc_range, np.array(voxel), 10)
+        out[f"refine_{tag}"] = U.norm_points(ref, pc_range, aniso, iso)
+        if aniso:
+            out["refine_raw"] = ref
+        np.random.seed(104)
+        out[f"refine_trunc_{tag}"] = U.norm_points(QH.aug_query_helper(helper, 1000, pc_range, np.array(voxel), 10), pc_range, aniso, iso)
+    save("g11_queries.npz", **out)
+
+
+if __name__ == "__main__":
+    main()
