@@ -194,6 +194,25 @@ int rald_query_refine(const float* helper_points, int64_t n_helper, int64_t aug_
                       const double* u_bias, const double* pc_range6_host, const double* voxel_size3_host, int32_t norm_anisotropy,
                       int32_t norm_isotropy, int32_t normalise, float* out_points, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Optimizer step of train_one_epoch (engine_generation.py:96-110) on FLAT fp32 storage: the model's
+ * parameters, gradients, Adam moments and the EMA copy are five arrays with one layout.
+ *   clip_grad_norm_ (utils/misc.py:262) -> torch.optim.AdamW(lr) (main_generation.py:161; betas 0.9/0.999,
+ *   eps 1e-8, weight_decay 0.01 defaults) -> update_ema(rate 0.999) (engine_generation.py:29-40, :110)
+ * ---------------------------------------------------------------------------------------- */
+/* *out_sumsq (device double) = sum g^2 (fp64 accumulation) */
+int rald_optim_grad_sumsq(const float* grads, int64_t n, double* out_sumsq, void* stream);
+/* out[0] = total_norm = sqrt(*sumsq) * pre_scale; out[1] = pre_scale * min(max_norm / (total_norm + 1e-6), 1)
+ * (max_norm <= 0: no clipping).  pre_scale folds the 1/world of a SUM all-reduce.  Device in, device out: no sync. */
+int rald_optim_clip_coef(const double* sumsq, float pre_scale, float max_norm, float* out_norm_coef, void* stream);
+/* one fused pass: g *= *grad_scale (device scalar, NULL = 1); p *= 1 - lr*wd; m, v updates; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps);
+ * ema = ema*rate + p*(1-rate) when ema_params != NULL.  step counts from 1.  write_back_grads != 0 stores the scaled gradient. */
+int rald_optim_adamw_ema(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema_params, int64_t n,
+                         const float* grad_scale, double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
+                         double ema_rate, int32_t write_back_grads, void* stream);
+/* update_ema alone (the reference also runs it on gradient-accumulation iterations) */
+int rald_optim_ema(float* ema_params, const float* params, int64_t n, double rate, void* stream);
+
 /* ColoRadarDataset.process_radar_data (datasets/aligned_coloradar/Coloradar_dataset.py:432-475): raw cube
  * [B,R,A,E,raw_channels] (intensity dB, doppler, ..., validity mask last; the .bin layout of load_radarcube
  * :420-430) -> the network's input [B,R,tgt_A,tgt_E,2]: intensity clipped to [0,max] / max, doppler * mask

@@ -74,6 +74,11 @@ SIGNATURES = {
     "rald_query_norm_points": (c_int, [c_void_p, c_i64, C.POINTER(C.c_double), c_int, c_int, c_void_p, c_void_p]),
     "rald_query_refine": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), c_int, c_int, c_int,
                                   c_void_p, c_void_p]),
+    "rald_optim_grad_sumsq": (c_int, [c_void_p, c_i64, c_void_p, c_void_p]),
+    "rald_optim_clip_coef": (c_int, [c_void_p, c_float, c_float, c_void_p, c_void_p]),
+    "rald_optim_adamw_ema": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, C.c_double, C.c_double, C.c_double,
+                                     C.c_double, C.c_double, c_i64, C.c_double, c_int, c_void_p]),
+    "rald_optim_ema": (c_int, [c_void_p, c_void_p, c_i64, C.c_double, c_void_p]),
     "rald_radar_cube_prepare": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_float, c_void_p,
                                         c_void_p]),
     "rald_op_gemm_nt": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p,

@@ -199,6 +199,27 @@ int rald_query_refine(const float* helper_points, int64_t n_helper, int64_t aug_
                         norm_isotropy, normalise, out_points, (hipStream_t)stream);
 }
 
+// ---- optimizer step on flat parameter storage --------------------------------------
+int rald_optim_grad_sumsq(const float* grads, int64_t n, double* out_sumsq, void* stream) {
+    RALD_CHECK(out_sumsq && (n == 0 || grads), "rald_optim_grad_sumsq: null argument");
+    return optim_grad_sumsq(grads, n, out_sumsq, (hipStream_t)stream);
+}
+int rald_optim_clip_coef(const double* sumsq, float pre_scale, float max_norm, float* out_norm_coef, void* stream) {
+    RALD_CHECK(sumsq && out_norm_coef, "rald_optim_clip_coef: null argument");
+    return optim_clip_coef(sumsq, pre_scale, max_norm, out_norm_coef, (hipStream_t)stream);
+}
+int rald_optim_adamw_ema(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema_params, int64_t n,
+                         const float* grad_scale, double lr, double beta1, double beta2, double eps, double weight_decay, int64_t step,
+                         double ema_rate, int32_t write_back_grads, void* stream) {
+    RALD_CHECK(n == 0 || (params && grads && exp_avg && exp_avg_sq), "rald_optim_adamw_ema: null argument");
+    return optim_adamw_ema(params, grads, exp_avg, exp_avg_sq, ema_params, n, grad_scale, lr, beta1, beta2, eps, weight_decay, step, ema_rate,
+                           write_back_grads, (hipStream_t)stream);
+}
+int rald_optim_ema(float* ema_params, const float* params, int64_t n, double rate, void* stream) {
+    RALD_CHECK(n == 0 || (ema_params && params), "rald_optim_ema: null argument");
+    return optim_ema(ema_params, params, n, rate, (hipStream_t)stream);
+}
+
 // ---- kernel-level entry points -----------------------------------------------------------------
 int rald_op_gemm_nt(const void* A, int64_t lda, int64_t strideA, const void* B, int64_t ldb, int64_t strideB,
                     void* C, int64_t ldc, int64_t strideC, const float* bias, int32_t M, int32_t N, int32_t K,

@@ -154,8 +154,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[MT][NT], const Ge
                     *reinterpret_cast<uint4*>(C) = v;
                 } else {
                     bf16* C = reinterpret_cast<bf16*>(a.C) + (int64_t)bz * a.strideC + (int64_t)m * a.ldc + c;
-                    if (c + 8 <= ncols) *reinterpret_cast<uint4*>(C) = v;
-                    else *reinterpret_cast<uint2*>(C) = make_uint2(v.x, v.y);   // N % 8 == 4 tail
+                    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                    if (c + 8 <= ncols) {
+                        if (a.ablate & 64) __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(C));
+                        else *reinterpret_cast<uint4*>(C) = v;
+                    } else *reinterpret_cast<uint2*>(C) = make_uint2(v.x, v.y);   // N % 8 == 4 tail
                 }
             }
         }
@@ -477,7 +480,16 @@ static int launch_glds(const GemmArgs& a, int epi, hipStream_t st) {
 
 // Host-side shape contract is checked here, before any launch (an out-of-bounds MFMA tile
 // can take the whole node down, so nothing is left to the kernel).
-int gemm_nt(const GemmArgs& a, int epi, hipStream_t st) {
+static int gemm_nt_impl(const GemmArgs& a, int epi, hipStream_t st);
+int gemm_nt(const GemmArgs& a0, int epi, hipStream_t st) {
+    // bf16 outputs are streamed (written once, read by the next kernel after the whole tensor has
+    // passed through): non-temporal stores keep them from evicting the weight panels out of L2.
+    static const int nt_store = getenv("RALD_NT_STORE") ? atoi(getenv("RALD_NT_STORE")) : 1;
+    GemmArgs a = a0;
+    if (nt_store) a.ablate |= 64;
+    return gemm_nt_impl(a, epi, st);
+}
+static int gemm_nt_impl(const GemmArgs& a, int epi, hipStream_t st) {
     RALD_CHECK(a.M > 0 && a.N > 0 && a.K > 0 && a.batch > 0, "gemm: empty problem");
     RALD_CHECK(a.K % 64 == 0, "gemm: K must be a multiple of 64 (pad with zeros)");
     RALD_CHECK(a.N % 4 == 0, "gemm: N must be a multiple of 4");

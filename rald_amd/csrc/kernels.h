@@ -111,4 +111,11 @@ int query_norm_points(const float* in, int64_t n, const double* pc_range, int an
 int query_refine(const float* pred, int64_t n_pred, int64_t aug_num, const int64_t* sel, const int64_t* scales, const double* u,
                  const double* pc_range, const double* voxel, int aniso, int iso, int normalise, float* out, hipStream_t st);
 
+// ---------------------------------------------------------------- optim.hip
+int optim_grad_sumsq(const float* g, int64_t n, double* out, hipStream_t st);
+int optim_clip_coef(const double* sumsq, float pre_scale, float max_norm, float* out2, hipStream_t st);
+int optim_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, int64_t n, const float* gscale, double lr, double beta1,
+                    double beta2, double eps, double wd, int64_t step, double ema_rate, int write_grad, hipStream_t st);
+int optim_ema(float* ema, const float* p, int64_t n, double rate, hipStream_t st);
+
 }  // namespace rald

@@ -237,6 +237,8 @@ def main():
         golden_radar_cube()
     if want("g11"):
         golden_queries()
+    if want("g12"):
+        golden_optim()
     print(f"done in {time.time() - t00:.0f}s")
 
 
@@ -364,6 +366,32 @@ def golden_queries():
         np.random.seed(104)
         out[f"refine_trunc_{tag}"] = U.norm_points(QH.aug_query_helper(helper, 1000, pc_range, np.array(voxel), 10), pc_range, aniso, iso)
     save("g11_queries.npz", **out)
+
+
+def golden_optim():
+    """G12: three iterations of the reference's optimizer step on CPU with torch's own pieces -
+    torch.nn.utils.clip_grad_norm_(params, 10) (utils/misc.py:262), torch.optim.AdamW(params, lr)
+    (main_generation.py:161, all other arguments default) and update_ema(rate=0.999)
+    (engine_generation.py:29-40, whose two lines are restated here: the module itself needs open3d)."""
+    shapes = [(128, 96), (1024,), (3, 3, 3, 8, 16), (7,), (1,)]
+    params = [torch.nn.Parameter(synth.normal(list(s), 900 + i)) for i, s in enumerate(shapes)]
+    ema = [p.detach().clone() for p in params]
+    opt = torch.optim.AdamW(params, lr=2.5e-4)
+    norms = []
+    for it in range(3):
+        scale = (40.0, 0.01, 3.0)[it]                        # first step clips, the others do not
+        for i, p in enumerate(params):
+            p.grad = synth.normal(list(p.shape), 1000 + 10 * it + i) * scale
+        norms.append(float(torch.nn.utils.clip_grad_norm_(params, 10.0)))
+        opt.step()
+        for t, s in zip(ema, params):
+            t.detach().mul_(0.999).add_(s.detach(), alpha=1 - 0.999)
+    out = {f"p{i}": p.detach() for i, p in enumerate(params)}
+    out.update({f"ema{i}": e for i, e in enumerate(ema)})
+    st = opt.state_dict()["state"]
+    out.update({f"m{i}": st[i]["exp_avg"] for i in range(len(params))})
+    out.update({f"v{i}": st[i]["exp_avg_sq"] for i in range(len(params))})
+    save("g12_optim.npz", norms=np.array(norms, np.float64), **out)
 
 
 if __name__ == "__main__":

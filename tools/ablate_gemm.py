@@ -19,6 +19,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "prio":
         for impl in (1, 3, 5):
             print(name, "impl%d" % impl, " ".join(f"abl{a}:{run(M,N,K,epi,impl,a):7.1f}us" for a in (0, 32, 0, 32)), flush=True)
     raise SystemExit
+if len(sys.argv) > 1 and sys.argv[1] == "nt":
+    for M in (16384, 32768):
+        for name,N,K,epi in [("ff1",4096,512,3),("qkv",1536,512,0),("q",512,512,0)]:
+            print(M, name, " ".join(f"abl{a}:{run(M,N,K,epi,5,a):7.1f}us" for a in (0, 64, 0, 64)), flush=True)
+    raise SystemExit
 if len(sys.argv) > 1 and sys.argv[1] == "epi":
     for impl in (1, 5):
         print("ff1 impl%d" % impl, " ".join(f"abl{a}:{run(M,4096,512,3,impl,a):7.1f}us" for a in (0, 8, 16, 24, 2)), flush=True)
