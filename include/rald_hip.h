@@ -230,6 +230,19 @@ int rald_op_gemm_nt(const void* A, int64_t lda, int64_t strideA, const void* B, 
                     void* C, int64_t ldc, int64_t strideC, const float* bias, int32_t M, int32_t N, int32_t K,
                     int32_t batch, float alpha, int32_t epilogue, void* stream);
 /* out_bf16 = LayerNorm(x_f32[M][D]) * (add_one + g[row/rows_per_group*gstride + c]) + b[...] */
+/* MXFP8 (OCP microscaling: e4m3 elements + one e8m0 scale per 32 consecutive K elements of a row), the
+ * "fp8 MFMA QKV/proj path" of BASELINE config #5.  C = alpha * A . B^T + bias on
+ * v_mfma_scale_f32_16x16x128_f8f6f4; epilogue 0 = bf16, 1 = f32, 2 = f32 residual accumulate.  K % 128 == 0;
+ * lda/ldb/strides in bytes (= elements); scales [rows][K/32] contiguous per batch entry. */
+int rald_op_gemm_mx8(const void* A8, const void* scaleA, int64_t lda, int64_t strideA, int64_t strideSA, const void* B8, const void* scaleB,
+                     int64_t ldb, int64_t strideB, int64_t strideSB, void* C, int64_t ldc, int64_t strideC, const float* bias, int32_t M,
+                     int32_t N, int32_t K, int32_t batch, float alpha, int32_t epilogue, void* stream);
+/* rows of f32 (in_is_bf16 = 0) or bf16 -> MXFP8: block scale = the smallest power of two with amax / scale <= 448 */
+int rald_op_quantize_mx8(const void* in, int32_t in_is_bf16, int64_t ld_in, void* out_e4m3, int64_t ld_out, void* out_scales_e8m0, int64_t rows,
+                         int32_t K, void* stream);
+/* rald_op_layernorm with an MXFP8 result (D = 512) */
+int rald_op_layernorm_mx8(const float* x, void* out_e4m3, void* out_scales_e8m0, int64_t M, int32_t D, const float* g, const float* b,
+                          int64_t gstride, int32_t rows_per_group, float add_one, float eps, void* stream);
 int rald_op_layernorm(const float* x, void* out_bf16, int32_t M, int32_t D, const float* g, const float* b,
                       int64_t gstride, int32_t rows_per_group, float add_one, float eps, void* stream);
 /* multi-head attention, head dim 64; Q[b][i][h*64+d], K[b][j][h*64+d], Vt[b][h*64+d][j] bf16 */

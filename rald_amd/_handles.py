@@ -304,3 +304,54 @@ class AeHandle:
         check(lib().rald_ae_decode_queries(self._h, C.c_void_p(_ptr(ctx)), C.c_void_p(_ptr(queries)), B, Q, C.c_void_p(_ptr(out)),
                                            C.c_void_p(_stream())))
         return out
+
+
+# ---- MXFP8 (OCP microscaling: e4m3 elements + one e8m0 scale per 32 K-elements) -----------------------
+def op_quantize_mx8(x: torch.Tensor):
+    """x [..., K] f32 or bf16 (last dim contiguous) -> (q uint8 [..., K] e4m3 bytes, scales uint8 [..., K/32] e8m0)."""
+    _need_cuda(x, "x")
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("op_quantize_mx8: float32 or bfloat16 input expected")
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K)
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    rows = x2.shape[0]
+    q = torch.empty(rows, K, device=x.device, dtype=torch.uint8)
+    s = torch.empty(rows, K // 32, device=x.device, dtype=torch.uint8)
+    check(lib().rald_op_quantize_mx8(C.c_void_p(_ptr(x2)), int(x.dtype == torch.bfloat16), x2.stride(0), C.c_void_p(_ptr(q)), K,
+                                     C.c_void_p(_ptr(s)), rows, K, C.c_void_p(_stream())))
+    return q.reshape(*x.shape), s.reshape(*x.shape[:-1], K // 32)
+
+
+def op_gemm_mx8(A8: torch.Tensor, sA: torch.Tensor, B8: torch.Tensor, sB: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                epilogue: int = 0, C_inout: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
+    """A8 [batch?,M,K] / B8 [batch?,N,K] uint8 (e4m3) with scales [.., K/32] uint8 (e8m0) -> C = alpha*A.B^T + bias.
+    epilogue 0 bf16, 1 f32, 2 f32 accumulate into C_inout."""
+    batched = A8.dim() == 3 or B8.dim() == 3
+    batch = (A8.shape[0] if A8.dim() == 3 else B8.shape[0]) if batched else 1
+    M, K = A8.shape[-2], A8.shape[-1]
+    N = B8.shape[-2]
+    if B8.shape[-1] != K or sA.shape[-1] != K // 32 or sB.shape[-1] != K // 32 or not (sA.is_contiguous() and sB.is_contiguous()):
+        raise ValueError("op_gemm_mx8: operand / scale shapes do not match")
+    if epilogue == 2:
+        out = C_inout
+    else:
+        shape = (batch, M, N) if batched else (M, N)
+        out = torch.empty(shape, device=A8.device, dtype=torch.bfloat16 if epilogue == 0 else torch.float32)
+    check(lib().rald_op_gemm_mx8(C.c_void_p(_ptr(A8)), C.c_void_p(_ptr(sA)), A8.stride(-2), A8.stride(0) if A8.dim() == 3 else 0,
+                                 sA.stride(0) if sA.dim() == 3 else 0, C.c_void_p(_ptr(B8)), C.c_void_p(_ptr(sB)), B8.stride(-2),
+                                 B8.stride(0) if B8.dim() == 3 else 0, sB.stride(0) if sB.dim() == 3 else 0, C.c_void_p(_ptr(out)),
+                                 out.stride(-2), out.stride(0) if out.dim() == 3 else 0, C.c_void_p(_ptr(bias) if bias is not None else 0),
+                                 M, N, K, batch, alpha, epilogue, C.c_void_p(_stream())))
+    return out
+
+
+def op_layernorm_mx8(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, gstride: int = 0, rows_per_group: int = 1,
+                     add_one: float = 0.0, eps: float = 1e-5):
+    M, D = x.shape
+    q = torch.empty(M, D, device=x.device, dtype=torch.uint8)
+    s = torch.empty(M, D // 32, device=x.device, dtype=torch.uint8)
+    check(lib().rald_op_layernorm_mx8(C.c_void_p(_ptr(x)), C.c_void_p(_ptr(q)), C.c_void_p(_ptr(s)), M, D, C.c_void_p(_ptr(g)),
+                                      C.c_void_p(_ptr(b)), gstride, rows_per_group, add_one, eps, C.c_void_p(_stream())))
+    return q, s

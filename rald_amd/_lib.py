@@ -83,6 +83,11 @@ SIGNATURES = {
                                         c_void_p]),
     "rald_op_gemm_nt": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p,
                                 c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "rald_op_gemm_mx8": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_void_p, c_i64, c_i64,
+                                 c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "rald_op_quantize_mx8": (c_int, [c_void_p, c_int, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p]),
+    "rald_op_layernorm_mx8": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p, c_i64, c_int, c_float, c_float,
+                                      c_void_p]),
     "rald_op_layernorm": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_i64, c_int, c_float, c_float, c_void_p]),
     "rald_op_attention": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64,
                                   c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),

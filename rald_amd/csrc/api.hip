@@ -231,6 +231,29 @@ int rald_op_gemm_nt(const void* A, int64_t lda, int64_t strideA, const void* B, 
     if (const char* e = getenv("RALD_GEMM_ABLATE")) g.ablate = atoi(e);
     return gemm_nt(g, epilogue, (hipStream_t)stream);
 }
+int rald_op_gemm_mx8(const void* A8, const void* scaleA, int64_t lda, int64_t strideA, int64_t strideSA, const void* B8, const void* scaleB,
+                     int64_t ldb, int64_t strideB, int64_t strideSB, void* C, int64_t ldc, int64_t strideC, const float* bias, int32_t M,
+                     int32_t N, int32_t K, int32_t batch, float alpha, int32_t epilogue, void* stream) {
+    RALD_CHECK(A8 && B8 && scaleA && scaleB && C, "rald_op_gemm_mx8: null pointer");
+    Mx8Args a;
+    a.A8 = (const unsigned char*)A8; a.B8 = (const unsigned char*)B8; a.SA = (const unsigned char*)scaleA; a.SB = (const unsigned char*)scaleB;
+    a.strideSA = strideSA; a.strideSB = strideSB;
+    GemmArgs& g = a.g;
+    g.A = nullptr; g.lda = lda; g.strideA = strideA; g.B = nullptr; g.ldb = ldb; g.strideB = strideB;
+    g.C = C; g.ldc = ldc; g.strideC = strideC; g.bias = bias; g.M = M; g.N = N; g.K = K; g.batch = batch; g.alpha = alpha; g.alpha_ncols = 1 << 30; g.ablate = 0;
+    return gemm_mx8(a, epilogue, (hipStream_t)stream);
+}
+int rald_op_quantize_mx8(const void* in, int32_t in_is_bf16, int64_t ld_in, void* out_e4m3, int64_t ld_out, void* out_scales_e8m0, int64_t rows,
+                         int32_t K, void* stream) {
+    RALD_CHECK(rows == 0 || (in && out_e4m3 && out_scales_e8m0), "rald_op_quantize_mx8: null pointer");
+    return quantize_mx8(in, in_is_bf16, ld_in, (unsigned char*)out_e4m3, ld_out, (unsigned char*)out_scales_e8m0, rows, K, (hipStream_t)stream);
+}
+int rald_op_layernorm_mx8(const float* x, void* out_e4m3, void* out_scales_e8m0, int64_t M, int32_t D, const float* g, const float* b,
+                          int64_t gstride, int32_t rows_per_group, float add_one, float eps, void* stream) {
+    RALD_CHECK(M == 0 || (x && out_e4m3 && out_scales_e8m0 && g && b), "rald_op_layernorm_mx8: null pointer");
+    return layernorm_mod_mx8(x, (unsigned char*)out_e4m3, (unsigned char*)out_scales_e8m0, M, D, g, b, gstride, rows_per_group, add_one, eps,
+                             (hipStream_t)stream);
+}
 int rald_op_layernorm(const float* x, void* out_bf16, int32_t M, int32_t D, const float* g, const float* b,
                       int64_t gstride, int32_t rows_per_group, float add_one, float eps, void* stream) {
     RALD_CHECK(x && out_bf16 && g && b, "rald_op_layernorm: null pointer");

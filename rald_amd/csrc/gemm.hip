@@ -28,6 +28,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "gemm_epilogue.h"
 
 namespace rald {
 
@@ -85,85 +86,6 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NT], const GemmAr
     }
 }
 
-
-// ---- LDS-staged epilogue (LDS-DMA engine): the MFMA accumulator layout gives every lane 4 columns
-// of 16 different rows, so direct stores touch 32-64 B per row per instruction (measured: 40 % of
-// the FF1 kernel).  Instead each wave transposes one 16-row m-tile at a time through a private LDS
-// patch (row stride padded by 16 B) and writes it back as whole rows, 16 B per lane: full 128-B
-// lines.  Wave-private, so no workgroup barrier; LDS ops of one wave execute in order.
-template <int MT, int NT, int EPI>
-__device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[MT][NT], const GemmArgs& a, int mb, int nb, int bz, int lane,
-                                                  unsigned char* patch) {
-    const int fr = lane & 15, fq = lane >> 4;
-    constexpr bool F32OUT = (EPI == EPI_F32 || EPI == EPI_RESID);
-    constexpr int OC = (EPI == EPI_GEGLU) ? NT * 8 : NT * 16;            // output columns of this wave
-    constexpr int ROWB = OC * (F32OUT ? 4 : 2);                          // bytes per output row
-    constexpr int STRIDE = ROWB + 16;
-    constexpr int LPR = ROWB / 16;                                       // lanes per row (16 B each)
-    constexpr int RPI = (64 / LPR) > 16 ? 16 : (64 / LPR);               // rows per store instruction (narrow tiles: lanes >= 16*LPR idle)
-    static_assert(ROWB % 16 == 0 && 64 % LPR == 0 && 16 % RPI == 0 && 16 * STRIDE <= 8704, "epilogue tiling");
-    const int oc0 = (EPI == EPI_GEGLU) ? nb / 2 : nb;                     // first output column
-    const int ncols = (EPI == EPI_GEGLU) ? a.N / 2 : a.N;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        // ---- lane-owned values -> LDS patch [16 rows][OC]
-        if constexpr (EPI == EPI_GEGLU) {
-#pragma unroll
-            for (int p = 0; p < NT / 2; ++p) {
-                const int nx = nb + 32 * p + 4 * fq;
-                const float4 bx = *reinterpret_cast<const float4*>(a.bias + nx);
-                const float4 bg = *reinterpret_cast<const float4*>(a.bias + nx + 16);
-                const f32x4 x = acc[i][2 * p], g = acc[i][2 * p + 1];
-                const f32x2 g01 = gelu_poly2(f32x2{g[0] + bg.x, g[1] + bg.y});
-                const f32x2 g23 = gelu_poly2(f32x2{g[2] + bg.z, g[3] + bg.w});
-                const f32x2 o01 = f32x2{x[0] + bx.x, x[1] + bx.y} * g01;
-                const f32x2 o23 = f32x2{x[2] + bx.z, x[3] + bx.w} * g23;
-                *reinterpret_cast<bf16x4*>(patch + fr * STRIDE + (16 * p + 4 * fq) * 2) = pack4(o01[0], o01[1], o23[0], o23[1]);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int n = nb + j * 16 + 4 * fq;
-                float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (a.bias && n < a.N) b = *reinterpret_cast<const float4*>(a.bias + n);
-                const f32x4 v = acc[i][j];
-                const float al = n < a.alpha_ncols ? a.alpha : 1.0f;
-                const float o0 = al * v[0] + b.x, o1 = al * v[1] + b.y, o2 = al * v[2] + b.z, o3 = al * v[3] + b.w;
-                if constexpr (F32OUT) *reinterpret_cast<float4*>(patch + fr * STRIDE + (16 * j + 4 * fq) * 4) = make_float4(o0, o1, o2, o3);
-                else *reinterpret_cast<bf16x4*>(patch + fr * STRIDE + (16 * j + 4 * fq) * 2) = pack4(o0, o1, o2, o3);
-            }
-        }
-        // ---- whole rows back out: lane -> (row lane/LPR, 16-byte piece lane%LPR)
-#pragma unroll
-        for (int r0 = 0; r0 < 16; r0 += RPI) {
-            const int r = r0 + lane / LPR, pc = lane % LPR;
-            if (lane / LPR >= RPI) continue;
-            const int m = mb + i * 16 + r;
-            const uint4 v = *reinterpret_cast<const uint4*>(patch + r * STRIDE + pc * 16);
-            constexpr int EPP = F32OUT ? 4 : 8;                           // elements per 16-byte piece
-            const int c = oc0 + pc * EPP;
-            if (m < a.M && c < ncols && !(a.ablate & 16)) {      // 16: diagnostics, no global stores
-                if constexpr (EPI == EPI_RESID) {
-                    float* C = reinterpret_cast<float*>(a.C) + (int64_t)bz * a.strideC + (int64_t)m * a.ldc + c;
-                    float4 x = *reinterpret_cast<float4*>(C);
-                    const float4 d = *reinterpret_cast<const float4*>(&v);
-                    x.x += d.x; x.y += d.y; x.z += d.z; x.w += d.w;
-                    *reinterpret_cast<float4*>(C) = x;
-                } else if constexpr (EPI == EPI_F32) {
-                    float* C = reinterpret_cast<float*>(a.C) + (int64_t)bz * a.strideC + (int64_t)m * a.ldc + c;
-                    *reinterpret_cast<uint4*>(C) = v;
-                } else {
-                    bf16* C = reinterpret_cast<bf16*>(a.C) + (int64_t)bz * a.strideC + (int64_t)m * a.ldc + c;
-                    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-                    if (c + 8 <= ncols) {
-                        if (a.ablate & 64) __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(C));
-                        else *reinterpret_cast<uint4*>(C) = v;
-                    } else *reinterpret_cast<uint2*>(C) = make_uint2(v.x, v.y);   // N % 8 == 4 tail
-                }
-            }
-        }
-    }
-}
 
 // =================================================================================================
 // register-staged engine (4 waves, 2x2)

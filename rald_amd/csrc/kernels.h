@@ -111,6 +111,19 @@ int query_norm_points(const float* in, int64_t n, const double* pc_range, int an
 int query_refine(const float* pred, int64_t n_pred, int64_t aug_num, const int64_t* sel, const int64_t* scales, const double* u,
                  const double* pc_range, const double* voxel, int aniso, int iso, int normalise, float* out, hipStream_t st);
 
+// ---------------------------------------------------------------- gemm_fp8.hip (MXFP8: e4m3 + e8m0 per 32 K-elements)
+struct Mx8Args {
+    GemmArgs g;                                    // shapes / C / bias / alpha as for gemm_nt; g.A, g.B unused; lda/ldb/strides in bytes
+    const unsigned char *A8, *B8;                  // [batch][M][K], [batch][N][K] e4m3
+    const unsigned char *SA, *SB;                  // [batch][M][K/32], [batch][N][K/32] e8m0
+    int64_t strideSA, strideSB;
+};
+int gemm_mx8(const Mx8Args& a, int epi, hipStream_t st);
+int quantize_mx8(const void* in, int in_is_bf16, int64_t ld_in, unsigned char* q, int64_t ld_q, unsigned char* scales, int64_t rows, int K,
+                 hipStream_t st);
+int layernorm_mod_mx8(const float* x, unsigned char* q, unsigned char* scales, int64_t rows, int D, const float* gam, const float* bet,
+                      int64_t gstride, int rows_per_group, float add_one, float eps, hipStream_t st);
+
 // ---------------------------------------------------------------- optim.hip
 int optim_grad_sumsq(const float* g, int64_t n, double* out, hipStream_t st);
 int optim_clip_coef(const double* sumsq, float pre_scale, float max_norm, float* out2, hipStream_t st);

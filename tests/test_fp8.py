@@ -1,0 +1,104 @@
+"""MXFP8 path (BASELINE config #5, "fp8 MFMA QKV/proj"): quantiser and GEMM on
+v_mfma_scale_f32_16x16x128_f8f6f4.  CPU: the MX oracle's element rounding against torch's own
+float8_e4m3fn conversion and format identities.  GPU: the HIP quantiser bit-exact against the oracle; the
+GEMM exact on integer data with power-of-two block scales, and within the MFMA's accumulation error
+(1e-4 relative to the output scale) of the oracle product on random data; edge shapes."""
+import numpy as np
+import pytest
+import torch
+
+from rald_amd import synth
+
+
+def test_mx_oracle_format_identities():
+    from oracle import mx_oracle as MX
+    x = synth.normal([64, 512], 300) * torch.logspace(-6, 6, 64)[:, None]
+    q, s = MX.quantize_mx8(x)
+    assert q.dtype == torch.uint8 and s.shape == (64, 16)
+    d = MX.dequantize_mx8(q, s)
+    blk = x.reshape(64, 16, 32)
+    amax = blk.abs().amax(-1)
+    scale = torch.pow(2.0, s.float() - 127)
+    assert torch.all(amax <= 448 * scale) and torch.all(amax > 224 * scale)             # smallest power of two that fits
+    err = (d - x).reshape(64, 16, 32).abs()
+    assert torch.all(err <= 16 * scale[..., None] * (1 + 1e-6))                          # half an ulp of the top binade [256, 448]
+    # powers of two and small integers survive exactly
+    ints = torch.randint(-8, 9, (16, 128), generator=torch.Generator().manual_seed(5)).float()
+    qi, si = MX.quantize_mx8(ints)
+    assert torch.equal(MX.dequantize_mx8(qi, si), ints)
+    z, sz = MX.quantize_mx8(torch.zeros(2, 64))
+    assert int(z.max()) == 0 and int(sz.max()) == 0
+
+
+@pytest.mark.gpu
+def test_hip_quantize_mx8_bit_exact_vs_oracle():
+    from oracle import mx_oracle as MX
+    from rald_amd import _handles as H
+    x = synth.normal([300, 512], 301) * torch.logspace(-5, 5, 300)[:, None]
+    x[7] = 0.0
+    x[8, 40:72] = 0.0
+    for t in (x, x.bfloat16(), synth.normal([3, 5, 64], 302), synth.normal([129, 1024], 303)):
+        q, s = H.op_quantize_mx8(t.cuda())
+        qo, so = MX.quantize_mx8(t.float())
+        assert torch.equal(s.cpu(), so) and torch.equal(q.cpu(), qo)
+    g, b = synth.normal([2, 512], 304) * 0.1, synth.normal([2, 512], 305) * 0.1
+    xx = synth.normal([2 * 96, 512], 306) * 3
+    q, s = H.op_layernorm_mx8(xx.cuda(), g.cuda(), b.cuda(), gstride=512, rows_per_group=96, add_one=1.0)
+    ref = torch.nn.functional.layer_norm(xx, (512,)).reshape(2, 96, 512) * (1 + g[:, None]) + b[:, None]
+    d = MX.dequantize_mx8(q.cpu(), s.cpu()).reshape(2, 96, 512)
+    qo, so = MX.quantize_mx8(ref)
+    # LN arithmetic differs in the last fp32 bits from torch's, which can flip an e4m3 rounding: compare values
+    assert float((d - MX.dequantize_mx8(qo, so)).abs().max()) <= float(ref.abs().max()) * 2 ** -3
+    assert float((d - ref).norm() / ref.norm()) < 4e-2
+    assert (s.cpu().reshape(2, 96, 16) == so).float().mean() > 0.999
+
+
+@pytest.mark.gpu
+def test_hip_gemm_mx8_exact_on_integers_and_vs_oracle():
+    from oracle import mx_oracle as MX
+    from rald_amd import _handles as H
+    gen = torch.Generator().manual_seed(11)
+    for (M, N, K, batch) in ((512, 512, 512, 1), (256, 768, 128, 1), (200, 260, 256, 1), (64, 512, 1024, 1), (512, 256, 512, 3)):
+        shp = lambda r: (batch, r, K) if batch > 1 else (r, K)
+        ia = torch.randint(-4, 5, shp(M), generator=gen).float()
+        ib = torch.randint(-4, 5, shp(N), generator=gen).float()
+        # random power-of-two block scales on top of integer data: exact in fp32
+        pa = torch.pow(2.0, torch.randint(-3, 4, (*shp(M)[:-1], K // 32), generator=gen).float())
+        pb = torch.pow(2.0, torch.randint(-3, 4, (*shp(N)[:-1], K // 32), generator=gen).float())
+        A = (ia.reshape(*pa.shape, 32) * pa[..., None]).reshape(shp(M))
+        B = (ib.reshape(*pb.shape, 32) * pb[..., None]).reshape(shp(N))
+        qa, sa = H.op_quantize_mx8(A.cuda())
+        qb, sb = H.op_quantize_mx8(B.cuda())
+        bias = torch.randint(-3, 4, (N,), generator=gen).float()
+        out = H.op_gemm_mx8(qa, sa, qb, sb, bias=bias.cuda(), epilogue=1).cpu()
+        want = (A.double() @ B.double().transpose(-1, -2) + bias.double()).float()
+        assert torch.equal(out, want), (M, N, K, batch)
+        acc = torch.ones_like(out).cuda()
+        H.op_gemm_mx8(qa, sa, qb, sb, bias=bias.cuda(), epilogue=2, C_inout=acc)
+        assert torch.equal(acc.cpu(), want + 1)
+    # random data: the MFMA sees exactly the dequantised operands
+    A, B = synth.normal([1024, 512], 310) * 2, synth.normal([1536, 512], 311) / 512 ** 0.5
+    qa, sa = H.op_quantize_mx8(A.cuda())
+    qb, sb = H.op_quantize_mx8(B.cuda())
+    out = H.op_gemm_mx8(qa, sa, qb, sb, epilogue=1, alpha=0.125).cpu().double()
+    want = MX.gemm_mx8(qa.cpu(), sa.cpu(), qb.cpu(), sb.cpu(), alpha=0.125)
+    # the MFMA's internal 128-deep dot product is not an IEEE fp32 sum: measured 2.3e-5 of the output scale
+    assert float((out - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    full = 0.125 * (A.double() @ B.double().T)
+    rel = float((out - full).norm() / full.norm())
+    print("MXFP8 GEMM vs fp64 product of the unquantised operands: rel-L2", rel)
+    assert rel < 5e-2
+    o16 = H.op_gemm_mx8(qa, sa, qb, sb, epilogue=0, alpha=0.125).float().cpu().double()
+    assert float((o16 - want).abs().max()) <= 2 ** -8 * float(want.abs().max()) * 1.01
+
+
+@pytest.mark.gpu
+def test_hip_gemm_mx8_rejects_bad_shapes():
+    from rald_amd import _handles as H
+    q, s = H.op_quantize_mx8(torch.zeros(64, 96, device="cuda"))
+    with pytest.raises(RuntimeError):
+        H.op_gemm_mx8(q, s, q, s)                                     # K = 96: not a multiple of 128
+    with pytest.raises(RuntimeError):
+        H.op_quantize_mx8(torch.zeros(4, 48, device="cuda"))          # K % 32 != 0
+    with pytest.raises(RuntimeError):
+        H.op_quantize_mx8(torch.zeros(4, 64))                         # CPU tensor
