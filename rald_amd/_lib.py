@@ -24,7 +24,7 @@ class DitConfig(C.Structure):
                 ("d_head", c_int), ("t_channels", c_int), ("context_dim", c_int),
                 ("n_cond_tokens", c_int), ("with_radar_enc", c_int), ("enc_hidden_ch", c_int),
                 ("enc_radar_ch", c_int), ("radar_r", c_int), ("radar_a", c_int), ("radar_e", c_int),
-                ("sigma_data", c_float)]
+                ("sigma_data", c_float), ("qkv_dtype", c_int)]
 
 
 class AeConfig(C.Structure):

@@ -17,7 +17,7 @@ int rald_version(void) { return 1; }
 void rald_dit_default_config(rald_dit_config* c) {
     c->n_latents = 512; c->channels = 32; c->depth = 24; c->n_heads = 8; c->d_head = 64; c->t_channels = 256;
     c->context_dim = 512; c->n_cond_tokens = 64; c->with_radar_enc = 1; c->enc_hidden_ch = 64; c->enc_radar_ch = 16;
-    c->radar_r = 128; c->radar_a = 64; c->radar_e = 32; c->sigma_data = 1.0f;
+    c->radar_r = 128; c->radar_a = 64; c->radar_e = 32; c->sigma_data = 1.0f; c->qkv_dtype = 0;
 }
 int rald_dit_create(const rald_dit_config* cfg, rald_dit** out) {
     RALD_CHECK(cfg && out, "rald_dit_create: null argument");

@@ -95,6 +95,7 @@ int Dit::create() {
     const auto& c = cfg;
     D = c.n_heads * c.d_head;
     RALD_CHECK(c.d_head == 64, "dit: only d_head = 64 is implemented");
+    RALD_CHECK(c.qkv_dtype == 0 || c.qkv_dtype == 1, "dit: qkv_dtype must be 0 (bf16) or 1 (MXFP8)");
     RALD_CHECK(D == 512, "dit: inner dim (n_heads*d_head) must be 512");
     RALD_CHECK(c.n_latents > 0 && c.n_latents % 64 == 0, "dit: n_latents must be a positive multiple of 64");
     RALD_CHECK(c.channels >= 1 && c.channels <= 64, "dit: channels must be in [1,64]");
@@ -118,6 +119,16 @@ int Dit::create() {
         l.b_ff1 = F32((size_t)8 * D);
         l.w_ff2 = B16((size_t)D * 4 * D);
         l.b_ff2 = F32(D);
+        if (c.qkv_dtype == 1) {
+            auto U8 = [&](size_t n) { return (unsigned char*)arena.alloc(n, true); };
+            l.q8_qk = U8((size_t)2 * D * D); l.s8_qk = U8((size_t)2 * D * D / 32);
+            l.q8_v = U8((size_t)D * D);      l.s8_v = U8((size_t)D * D / 32);
+            l.q8_o = U8((size_t)D * D);      l.s8_o = U8((size_t)D * D / 32);
+            l.q8_q2 = U8((size_t)D * D);     l.s8_q2 = U8((size_t)D * D / 32);
+            l.q8_o2 = U8((size_t)D * D);     l.s8_o2 = U8((size_t)D * D / 32);
+            RALD_CHECK(l.q8_qk && l.s8_qk && l.q8_v && l.s8_v && l.q8_o && l.s8_o && l.q8_q2 && l.s8_q2 && l.q8_o2 && l.s8_o2,
+                       "dit: device allocation failed");
+        }
     }
     w_k2_all = B16((size_t)L * D * c.context_dim);
     w_v2_all = B16((size_t)L * D * c.context_dim);
@@ -225,6 +236,16 @@ int Dit::load_weight(const std::string& name, const float* data, int64_t nelem) 
 
 int Dit::finalize() {
     for (const auto& k : expected) RALD_CHECK(loaded.count(k), "dit: missing key '" + k + "' (strict load)");
+    if (cfg.qkv_dtype == 1) {                  // MXFP8 copies of the attention projections, from the bf16 weights
+        for (auto& l : layers) {
+            RALD_TRY(quantize_mx8(l.w_qk, 1, D, l.q8_qk, D, l.s8_qk, 2 * D, D, nullptr));
+            RALD_TRY(quantize_mx8(l.w_v, 1, D, l.q8_v, D, l.s8_v, D, D, nullptr));
+            RALD_TRY(quantize_mx8(l.w_o, 1, D, l.q8_o, D, l.s8_o, D, D, nullptr));
+            RALD_TRY(quantize_mx8(l.w_q2, 1, D, l.q8_q2, D, l.s8_q2, D, D, nullptr));
+            RALD_TRY(quantize_mx8(l.w_o2, 1, D, l.q8_o2, D, l.s8_o2, D, D, nullptr));
+        }
+        RALD_HIP(hipDeviceSynchronize());
+    }
     finalized = true;
     return 0;
 }
@@ -232,6 +253,8 @@ int Dit::finalize() {
 int Dit::reserve(int B) {
     if (B <= ws_batch) return 0;
     RALD_HIP(hipDeviceSynchronize());
+    for (void* p : {(void*)ws_h8, (void*)ws_hs, (void*)ws_o8, (void*)ws_os})
+        if (p) arena.release(p);
     for (void* p : {(void*)ws_x, (void*)ws_h, (void*)ws_qk, (void*)ws_vt, (void*)ws_o, (void*)ws_q2, (void*)ws_g, (void*)ws_tok,
                     (void*)ws_xcur, (void*)ws_xeul, (void*)ws_den, (void*)ws_dcur})
         if (p) arena.release(p);
@@ -251,6 +274,13 @@ int Dit::reserve(int B) {
     ws_dcur = (float*)arena.alloc(nl * 4, true);
     RALD_CHECK(ws_x && ws_h && ws_qk && ws_vt && ws_o && ws_q2 && ws_g && ws_tok && ws_xcur && ws_xeul && ws_den && ws_dcur,
                "dit: workspace allocation failed");
+    if (cfg.qkv_dtype == 1) {
+        ws_h8 = (unsigned char*)arena.alloc(M * D, true);
+        ws_hs = (unsigned char*)arena.alloc(M * D / 32, true);
+        ws_o8 = (unsigned char*)arena.alloc(M * D, true);
+        ws_os = (unsigned char*)arena.alloc(M * D / 32, true);
+        RALD_CHECK(ws_h8 && ws_hs && ws_o8 && ws_os, "dit: workspace allocation failed");
+    }
     ws_batch = B;
     return 0;
 }
@@ -377,6 +407,65 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
         return 0;
     };
     RALD_TRY(proj_in(x, w_in, ws_x, M, C, D, coef, cstride, NL, st));
+    if (cfg.qkv_dtype == 1) {
+        // ---- MXFP8 attention projections (BASELINE config #5).  The AdaLN outputs that feed q/k/v (norm1,
+        // norm2) and the attention outputs that feed to_out are quantised to e4m3 + e8m0/32 and multiplied on
+        // v_mfma_scale_f32_16x16x128_f8f6f4; the feed-forward stays bf16.  First version: the quantisers are
+        // separate passes (LayerNorm -> MXFP8 in one kernel, attention output in its own), not yet fused into
+        // the producing GEMM / attention epilogues.
+        auto ln8 = [&](const float* m) { return layernorm_mod_mx8(ws_x, ws_h8, ws_hs, M, D, m, m + D, gstride, NL, 1.0f, 1e-5f, st); };
+        auto mx = [&](const unsigned char* A8, const unsigned char* SA, const unsigned char* B8, const unsigned char* SB, void* Cp, int64_t ldc,
+                      const float* bias, int m, int n) {
+            Mx8Args a;
+            a.A8 = A8; a.SA = SA; a.B8 = B8; a.SB = SB; a.strideSA = 0; a.strideSB = 0;
+            a.g = gemm_args(nullptr, D, nullptr, D, Cp, ldc, bias, m, n, D);
+            return a;
+        };
+        auto out_proj8 = [&](const unsigned char* W8, const unsigned char* S8, const float* bias) -> int {
+            RALD_TRY(quantize_mx8(ws_o, 1, D, ws_o8, D, ws_os, M, D, st));
+            return gemm_mx8(mx(ws_o8, ws_os, W8, S8, ws_x, D, bias, M, D), EPI_RESID, st);
+        };
+        RALD_TRY(ln8(mod));                                                               // norm1 of block 0
+        for (int li = 0; li < L; ++li) {
+            const Layer& l = layers[li];
+            const float* m2 = mod + (int64_t)(li * 3 + 1) * 2 * D;
+            const float* m3 = mod + (int64_t)(li * 3 + 2) * 2 * D;
+            Mx8Args qk = mx(ws_h8, ws_hs, l.q8_qk, l.s8_qk, ws_qk, 2 * D, nullptr, M, 2 * D);
+            qk.g.alpha = qscale; qk.g.alpha_ncols = D;
+            RALD_TRY(gemm_mx8(qk, EPI_BF16, st));
+            Mx8Args vt = mx(l.q8_v, l.s8_v, ws_h8, ws_hs, ws_vt, NL, nullptr, D, NL);    // V^T = Wv . h^T per sample
+            vt.g.batch = B; vt.g.strideB = (int64_t)NL * D; vt.strideSB = (int64_t)NL * D / 32; vt.g.strideC = (int64_t)D * NL;
+            RALD_TRY(gemm_mx8(vt, EPI_BF16, st));
+            AttnArgs a1;
+            a1.Q = ws_qk; a1.ldq = 2 * D; a1.strideQ = (int64_t)NL * 2 * D;
+            a1.K = ws_qk + D; a1.ldk = 2 * D; a1.strideK = (int64_t)NL * 2 * D;
+            a1.Vt = ws_vt; a1.ldvt = NL; a1.strideVt = (int64_t)D * NL;
+            a1.O = ws_o; a1.ldo = D; a1.strideO = (int64_t)NL * D;
+            a1.nq = NL; a1.nk = NL; a1.k_rows = NL; a1.heads = cfg.n_heads; a1.batch = B; a1.scale = scale; a1.q_prescaled = 1;
+            RALD_TRY(attention_d64(a1, st));
+            RALD_TRY(out_proj8(l.q8_o, l.s8_o, l.b_o));
+            RALD_TRY(ln8(m2));
+            Mx8Args q2 = mx(ws_h8, ws_hs, l.q8_q2, l.s8_q2, ws_q2, D, nullptr, M, D);
+            q2.g.alpha = qscale;
+            RALD_TRY(gemm_mx8(q2, EPI_BF16, st));
+            AttnArgs a2;
+            a2.Q = ws_q2; a2.ldq = D; a2.strideQ = (int64_t)NL * D;
+            a2.K = Kc + (size_t)li * D; a2.ldk = (int64_t)L * D; a2.strideK = (int64_t)T * L * D;
+            a2.Vt = Vtc + (size_t)li * D * T; a2.ldvt = T; a2.strideVt = (int64_t)L * D * T;
+            a2.O = ws_o; a2.ldo = D; a2.strideO = (int64_t)NL * D;
+            a2.nq = NL; a2.nk = T; a2.k_rows = T; a2.heads = cfg.n_heads; a2.batch = B; a2.scale = scale; a2.q_prescaled = 1;
+            RALD_TRY(attention_d64(a2, st));
+            RALD_TRY(out_proj8(l.q8_o2, l.s8_o2, l.b_o2));
+            RALD_TRY(layernorm_mod(ws_x, ws_h, M, D, m3, m3 + D, gstride, NL, 1.0f, 1e-5f, st));     // norm3 feeds the bf16 feed-forward
+            GemmArgs f1 = gemm_args(ws_h, D, l.w_ff1, D, ws_g, 4 * D, l.b_ff1, M, 8 * D, D);
+            RALD_TRY(gemm_nt(f1, EPI_GEGLU, st));
+            GemmArgs f2 = gemm_args(ws_g, 4 * D, l.w_ff2, 4 * D, ws_x, D, l.b_ff2, M, D, 4 * D);
+            RALD_TRY(gemm_nt(f2, EPI_RESID, st));
+            if (li + 1 < L) RALD_TRY(ln8(mod + (int64_t)((li + 1) * 3) * 2 * D));        // norm1 of the next block
+        }
+        RALD_TRY(final_norm_proj(ws_x, norm_g, norm_b, w_out, x, out, M, D, C, coef, cstride, NL, st));
+        return 0;
+    }
     RALD_TRY(layernorm_mod(ws_x, ws_h, M, D, mod, mod + D, gstride, NL, 1.0f, 1e-5f, st));      // norm1 of block 0
     for (int li = 0; li < L; ++li) {
         const Layer& l = layers[li];

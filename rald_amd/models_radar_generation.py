@@ -11,6 +11,8 @@ a CPU tensor, or without the library, calls raise.
 """
 from __future__ import annotations
 
+import os
+
 import math
 from typing import Optional
 
@@ -72,6 +74,12 @@ class _HipBacked(nn.Module):
 # ----------------------------------------------------------------------------------------------
 # LatentArrayTransformer (:171-233)
 # ----------------------------------------------------------------------------------------------
+def _qkv_code(name: str) -> int:
+    if name not in ("bf16", "fp8"):
+        raise ValueError("qkv_dtype must be 'bf16' or 'fp8'")
+    return 1 if name == "fp8" else 0
+
+
 class LatentArrayTransformer(_HipBacked):
     def __init__(self, in_channels, t_channels, n_heads, d_head, depth=1, dropout=0., context_dim=None,
                  out_channels=None, _owner=None):
@@ -85,6 +93,7 @@ class LatentArrayTransformer(_HipBacked):
         self.context_dim = context_dim
         self.depth, self.n_heads, self.d_head = depth, n_heads, d_head
         object.__setattr__(self, "_owner", _owner)      # EDMPrecond that shares its handle (not a submodule)
+        self.qkv_dtype = os.environ.get("RALD_QKV_DTYPE", "bf16")   # "bf16" | "fp8" (MXFP8 q/k/v/out projections, BASELINE config #5)
         self._hip = None
         self._hip_fp = None
         spec = _w.dit_spec(channels=in_channels, depth=depth, n_heads=n_heads, d_head=d_head, t_channels=t_channels,
@@ -97,12 +106,12 @@ class LatentArrayTransformer(_HipBacked):
                          d_head=self.d_head, t_channels=self.t_channels,
                          context_dim=D if self.context_dim is None else self.context_dim,
                          n_cond_tokens=n_cond_tokens, with_radar_enc=0, enc_hidden_ch=64, enc_radar_ch=16,
-                         radar_r=128, radar_a=64, radar_e=32, sigma_data=1.0)
+                         radar_r=128, radar_a=64, radar_e=32, sigma_data=1.0, qkv_dtype=_qkv_code(self.qkv_dtype))
 
     def _handle(self, n_latents: int, n_cond_tokens: int) -> DitHandle:
         if self._owner is not None:
             return self._owner._handle()
-        fp = (self._state_fingerprint(), n_latents, n_cond_tokens)
+        fp = (self._state_fingerprint(), n_latents, n_cond_tokens, self.qkv_dtype)
         if self._hip is None or self._hip_fp != fp:
             h = DitHandle(self._config(n_latents, n_cond_tokens))
             h.load(("model." + k, v) for k, v in self.state_dict().items())
@@ -204,6 +213,7 @@ class EDMPrecond(_HipBacked):
                            enc_radar_ch=self.configs.enc_radar_ch, radar_token_channel=self.radar_token_channel,
                            rae=(self.configs.enc_radar_r_dim, self.configs.enc_radar_a_dim, self.configs.enc_radar_e_dim))
         build_param_tree(self, [(n, s) for n, s in rest if not n.startswith("model.")])
+        self.qkv_dtype = os.environ.get("RALD_QKV_DTYPE", "bf16")   # "bf16" | "fp8": see LatentArrayTransformer
         self._hip = None
         self._hip_fp = None
         self._cond_memo = None
@@ -215,10 +225,11 @@ class EDMPrecond(_HipBacked):
                          d_head=self.d_head, t_channels=256, context_dim=self.radar_token_channel,
                          n_cond_tokens=c.enc_radar_r_dim * c.enc_radar_a_dim * c.enc_radar_e_dim, with_radar_enc=1,
                          enc_hidden_ch=c.enc_hidden_ch, enc_radar_ch=c.enc_radar_ch, radar_r=c.input_radar_r_dim,
-                         radar_a=c.input_radar_a_dim, radar_e=c.input_radar_e_dim, sigma_data=float(self.sigma_data))
+                         radar_a=c.input_radar_a_dim, radar_e=c.input_radar_e_dim, sigma_data=float(self.sigma_data),
+                         qkv_dtype=_qkv_code(self.qkv_dtype))
 
     def _handle(self) -> DitHandle:
-        fp = self._state_fingerprint()
+        fp = (self._state_fingerprint(), self.qkv_dtype)
         if self._hip is None or self._hip_fp != fp:
             h = DitHandle(self._config())
             h.load(self.state_dict().items())

@@ -102,3 +102,40 @@ def test_hip_gemm_mx8_rejects_bad_shapes():
         H.op_quantize_mx8(torch.zeros(4, 48, device="cuda"))          # K % 32 != 0
     with pytest.raises(RuntimeError):
         H.op_quantize_mx8(torch.zeros(4, 64))                         # CPU tensor
+
+
+@pytest.mark.gpu
+def test_fp8_qkv_mode_vs_reference_goldens():
+    """BASELINE config #5: the denoiser with MXFP8 attention projections (qkv_dtype='fp8') against the SAME
+    fp32 goldens as the bf16 mode (SURVEY.md §8d 'fp8: same three numbers').  Stated tolerances for this mode:
+    one NFE D_x rel-L2 <= 1e-1 (measured 6.9e-2 / 6.0e-2 / 1.4e-4 at sigma 80 / 1 / 0.002), 18-step sampler
+    <= 1e-1 (measured 4.6e-2), raw F_x within 1.5e-1 of the bf16 mode (measured 8.8e-2 on these random
+    weights).  e4m3 keeps 3 mantissa bits: ~3.8 % per projection (test_hip_gemm_mx8_*), 120 projections per NFE."""
+    from conftest import load_golden, rel_l2
+    from rald_amd import config, models_radar_generation as G, weights
+    m = G.LatentArrayTransformer(in_channels=32, t_channels=256, n_heads=8, d_head=64, depth=24)
+    m.load_state_dict(weights.make_state_dict(weights.dit_spec(depth=24, with_radar=False, prefix=""), 0), strict=True)
+    m = m.cuda()
+    x, t, cond = synth.latents([0, 1]).cuda(), torch.tensor([0.25, -1.0]), synth.cond_tokens(2).cuda()
+    out16 = m(x, t, cond=cond)
+    m.qkv_dtype = "fp8"
+    out8 = m(x, t, cond=cond)
+    print("fp8 vs bf16 mode, raw F_x rel_l2:", rel_l2(out8, out16))
+    assert 1e-4 < rel_l2(out8, out16) < 1.5e-1                        # the mode really changes the arithmetic
+    edm = G.EDMPrecond(n_latents=512, channels=32, depth=24, configs=config.shipped_generation_config())
+    edm.load_state_dict(weights.make_state_dict(weights.dit_spec(depth=24), 0), strict=True)
+    edm = edm.cuda()
+    edm.qkv_dtype = "fp8"
+    g3, g4 = load_golden("g3_precond.npz"), load_golden("g4_sample18.npz")
+    cube = synth.radar_cube(2).cuda()
+    for s in (80.0, 1.0, 0.002):
+        err = rel_l2(edm(x * max(s, 1.0), torch.tensor(s), cube, "radar"), g3[f"d_sigma_{s}"])
+        print(f"fp8 mode, sigma {s}: D_x rel_l2 {err}")
+        assert err < 1e-1
+    smp = edm.sample(cond=cube, batch_seeds=None, cond_type="radar")
+    err = rel_l2(smp, g4["sample"])
+    print("fp8 mode, 18-step sampler rel_l2", err)
+    assert err < 1e-1
+    with pytest.raises(ValueError):
+        m.qkv_dtype = "int4"
+        m(x, t, cond=cond)
