@@ -366,9 +366,9 @@ int Ae::decode_latents(const float* z, int B, void* ctx, hipStream_t st) {
     const float scale = 1.0f / sqrtf((float)cfg.dim_head);
     RALD_TRY(small_k_linear(z, w_proj, b_proj, x_x, BM, L, d, st));                     // x = proj(z)  (:410)
     static const bool fuse_env = !(getenv("RALD_FUSE_LN") && atoi(getenv("RALD_FUSE_LN")) == 0);
-    const bool fuse_ln = fuse_env && d == 512 && gemm_resid_ln_pays(BM);   // the fused epilogue owns whole 512-wide rows
+    const bool fuse_ok = fuse_env && d == 512;                              // the fused epilogue owns whole 512-wide rows
     auto resid_ln = [&](const bf16* A, int64_t lda, const bf16* W, int64_t ldw, const float* bias, int K, const float* ng, const float* nb) -> int {
-        if (fuse_ln) {
+        if (fuse_ok && gemm_resid_ln_pays(BM, K)) {
             GemmLnArgs g;
             g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.x = x_x; g.h = x_h;
             g.g = ng; g.b = nb; g.gstride = 0; g.rows_per_group = 1 << 30; g.add_one = 0.f; g.eps = 1e-5f; g.M = BM; g.K = K;

@@ -394,7 +394,7 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
     static const bool fuse_ln = !(getenv("RALD_FUSE_LN") && atoi(getenv("RALD_FUSE_LN")) == 0);
     auto resid_ln = [&](const bf16* A, int64_t lda, const bf16* W, int64_t ldw, const float* bias, int K, const float* mnext) -> int {
         // x += A.W^T + bias, then (if mnext) h = AdaLN(x; mnext) for the next sub-block
-        if (fuse_ln && mnext && gemm_resid_ln_pays(M)) {
+        if (fuse_ln && mnext && gemm_resid_ln_pays(M, K)) {
             GemmLnArgs g;
             g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.x = ws_x; g.h = ws_h;
             g.g = mnext; g.b = mnext + D; g.gstride = gstride; g.rows_per_group = NL; g.add_one = 1.0f; g.eps = 1e-5f;

@@ -37,8 +37,9 @@ struct GemmLnArgs {
     int M, K;
 };
 int gemm_resid_ln(const GemmLnArgs& a, hipStream_t st);
-// true when the fused kernel beats GEMM + separate LayerNorm (its 128-row tiles must cover the chip; measured on MI355X)
-inline bool gemm_resid_ln_pays(int M) { return M >= 192 * 128; }
+// true when the fused kernel beats GEMM + separate LayerNorm (measured on MI355X, tools/bench_resid_ln.py and
+// whole-NFE sweeps: wins from M = 16384 on for K = 512 and K = 2048, +1 % per NFE at B = 32; at M = 8192 it loses)
+inline bool gemm_resid_ln_pays(int M, int K = 512) { (void)K; return M >= 16384; }
 
 // ---------------------------------------------------------------- norm.hip
 // out_bf16[m][c] = LN(x[m])[c] * (add_one + g[s][c]) + b[s][c],  s = (m / rows_per_group) * gstride
