@@ -231,6 +231,31 @@ int rald_op_gemm_nt(const void* A, int64_t lda, int64_t strideA, const void* B, 
                     void* C, int64_t ldc, int64_t strideC, const float* bias, int32_t M, int32_t N, int32_t K,
                     int32_t batch, float alpha, int32_t epilogue, void* stream);
 /* out_bf16 = LayerNorm(x_f32[M][D]) * (add_one + g[row/rows_per_group*gstride + c]) + b[...] */
+/* rald_op_gemm_nt with an inner batch (attention heads): grid z = batch * batch2, operand offset =
+ * b1 * stride + b2 * stride2 */
+int rald_op_gemm_nt2(const void* A, int64_t lda, int64_t strideA, int64_t strideA2, const void* B, int64_t ldb, int64_t strideB, int64_t strideB2,
+                     void* C, int64_t ldc, int64_t strideC, int64_t strideC2, const float* bias, int32_t M, int32_t N, int32_t K, int32_t batch,
+                     int32_t batch2, float alpha, int32_t epilogue, void* stream);
+/* Backward building blocks of the transformer block (what autograd derives for
+ * models_radar_generation.py:35-169).  dX = dY.W and dW = dY^T.X run on rald_op_gemm_nt with transposed operands. */
+/* in [batch][batch2][rows][cols] (f32 or bf16) -> out [batch][batch2][cols][rows] bf16 */
+int rald_op_transpose(const void* in, int32_t in_is_bf16, int64_t ld_in, int64_t stride_in, int64_t stride_in2, void* out_bf16, int64_t ld_out,
+                      int64_t stride_out, int64_t stride_out2, int32_t rows, int32_t cols, int32_t batch, int32_t batch2, void* stream);
+/* AdaLayerNorm :119-131 (add_one = 1) / LayerNorm (add_one = 0, scale = weight) backward, D = 512:
+ * dx += ..., dscale[g] += sum_rows dh * xhat, dshift[g] += sum_rows dh  (g = row / rows_per_group, stride gstride) */
+int rald_op_ln_mod_bwd(const float* x, const float* dh, const float* scale, int64_t gstride, int32_t rows_per_group, float add_one, float eps,
+                       int64_t rows, int32_t D, float* dx_accum, float* dscale_accum, float* dshift_accum, void* stream);
+/* GEGLU :88-95 in the natural layout u = [a | g] (2*inner columns): hid = a * gelu_erf(g); and its backward */
+int rald_op_geglu_fwd(const void* u_bf16, void* hid_bf16, int64_t M, int32_t inner, void* stream);
+int rald_op_geglu_bwd(const void* u_bf16, const void* dhid_bf16, void* du_bf16, int64_t M, int32_t inner, void* stream);
+/* bias gradient: out[n] += sum_m X[m][n] */
+int rald_op_colsum(const void* X, int32_t is_bf16, int64_t ld, int64_t M, int32_t N, float* out_accum, void* stream);
+/* attention backward, element-wise parts: lse[r] = log sum_c exp(scale*S[r][c]); delta[b][h][q] = <dO, O> over head h of row m = b*nq + q;
+ * P = exp(scale*S - lse[i]), dS = P*(dP - delta[i])*scale with i = row (by_col 0) or column (by_col 1) */
+int rald_op_row_lse(const float* S, int64_t rows, int32_t cols, float scale, float* lse, void* stream);
+int rald_op_rowdot_heads(const void* dO_bf16, const void* O_bf16, int64_t M, int32_t heads, int32_t nq, float* delta, void* stream);
+int rald_op_attn_bwd_elem(const float* S, const float* dP, const float* lse, const float* delta, int64_t batch, int32_t R, int32_t Ccols,
+                          int64_t vbatch_stride, int32_t vstride, float scale, int32_t by_col, void* P_bf16, void* dS_bf16, void* stream);
 /* MXFP8 (OCP microscaling: e4m3 elements + one e8m0 scale per 32 consecutive K elements of a row), the
  * "fp8 MFMA QKV/proj path" of BASELINE config #5.  C = alpha * A . B^T + bias on
  * v_mfma_scale_f32_16x16x128_f8f6f4; epilogue 0 = bf16, 1 = f32, 2 = f32 residual accumulate.  K % 128 == 0;

@@ -83,6 +83,18 @@ SIGNATURES = {
                                         c_void_p]),
     "rald_op_gemm_nt": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p,
                                 c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "rald_op_gemm_nt2": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_i64, c_i64, c_i64, c_void_p, c_i64, c_i64, c_i64, c_void_p,
+                                 c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "rald_op_transpose": (c_int, [c_void_p, c_int, c_i64, c_i64, c_i64, c_void_p, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_void_p]),
+    "rald_op_ln_mod_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_float, c_float, c_i64, c_int, c_void_p, c_void_p, c_void_p,
+                                   c_void_p]),
+    "rald_op_geglu_fwd": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p]),
+    "rald_op_geglu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
+    "rald_op_colsum": (c_int, [c_void_p, c_int, c_i64, c_i64, c_int, c_void_p, c_void_p]),
+    "rald_op_row_lse": (c_int, [c_void_p, c_i64, c_int, c_float, c_void_p, c_void_p]),
+    "rald_op_rowdot_heads": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p]),
+    "rald_op_attn_bwd_elem": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_i64, c_int, c_float, c_int, c_void_p,
+                                      c_void_p, c_void_p]),
     "rald_op_gemm_mx8": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_void_p, c_i64, c_i64,
                                  c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "rald_op_quantize_mx8": (c_int, [c_void_p, c_int, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p]),

@@ -231,6 +231,51 @@ int rald_op_gemm_nt(const void* A, int64_t lda, int64_t strideA, const void* B, 
     if (const char* e = getenv("RALD_GEMM_ABLATE")) g.ablate = atoi(e);
     return gemm_nt(g, epilogue, (hipStream_t)stream);
 }
+int rald_op_gemm_nt2(const void* A, int64_t lda, int64_t strideA, int64_t strideA2, const void* B, int64_t ldb, int64_t strideB, int64_t strideB2,
+                     void* C, int64_t ldc, int64_t strideC, int64_t strideC2, const float* bias, int32_t M, int32_t N, int32_t K, int32_t batch,
+                     int32_t batch2, float alpha, int32_t epilogue, void* stream) {
+    RALD_CHECK(A && B && C, "rald_op_gemm_nt2: null pointer");
+    GemmArgs g = gemm_args((const bf16*)A, lda, (const bf16*)B, ldb, C, ldc, bias, M, N, K);
+    g.strideA = strideA; g.strideB = strideB; g.strideC = strideC; g.batch = batch; g.alpha = alpha;
+    g.batch2 = batch2; g.strideA2 = strideA2; g.strideB2 = strideB2; g.strideC2 = strideC2;
+    return gemm_nt(g, epilogue, (hipStream_t)stream);
+}
+int rald_op_transpose(const void* in, int32_t in_is_bf16, int64_t ld_in, int64_t stride_in, int64_t stride_in2, void* out_bf16, int64_t ld_out,
+                      int64_t stride_out, int64_t stride_out2, int32_t rows, int32_t cols, int32_t batch, int32_t batch2, void* stream) {
+    TransposeArgs a;
+    a.in = in; a.ld_in = ld_in; a.stride_in = stride_in; a.stride_in2 = stride_in2; a.out = (bf16*)out_bf16; a.ld_out = ld_out;
+    a.stride_out = stride_out; a.stride_out2 = stride_out2; a.rows = rows; a.cols = cols; a.batch = batch; a.batch2 = batch2;
+    return transpose_rows(a, in_is_bf16, (hipStream_t)stream);
+}
+int rald_op_ln_mod_bwd(const float* x, const float* dh, const float* scale, int64_t gstride, int32_t rows_per_group, float add_one, float eps,
+                       int64_t rows, int32_t D, float* dx_accum, float* dscale_accum, float* dshift_accum, void* stream) {
+    RALD_CHECK(x && dh && scale && dx_accum && dscale_accum && dshift_accum, "rald_op_ln_mod_bwd: null pointer");
+    return ln_mod_bwd(x, dh, scale, gstride, rows_per_group, add_one, eps, rows, D, dx_accum, dscale_accum, dshift_accum, (hipStream_t)stream);
+}
+int rald_op_geglu_fwd(const void* u_bf16, void* hid_bf16, int64_t M, int32_t inner, void* stream) {
+    RALD_CHECK(u_bf16 && hid_bf16, "rald_op_geglu_fwd: null pointer");
+    return geglu_fwd((const bf16*)u_bf16, (bf16*)hid_bf16, M, inner, (hipStream_t)stream);
+}
+int rald_op_geglu_bwd(const void* u_bf16, const void* dhid_bf16, void* du_bf16, int64_t M, int32_t inner, void* stream) {
+    RALD_CHECK(u_bf16 && dhid_bf16 && du_bf16, "rald_op_geglu_bwd: null pointer");
+    return geglu_bwd((const bf16*)u_bf16, (const bf16*)dhid_bf16, (bf16*)du_bf16, M, inner, (hipStream_t)stream);
+}
+int rald_op_colsum(const void* X, int32_t is_bf16, int64_t ld, int64_t M, int32_t N, float* out_accum, void* stream) {
+    return colsum(X, is_bf16, ld, M, N, out_accum, (hipStream_t)stream);
+}
+int rald_op_row_lse(const float* S, int64_t rows, int32_t cols, float scale, float* lse, void* stream) {
+    RALD_CHECK(S && lse, "rald_op_row_lse: null pointer");
+    return row_lse(S, rows, cols, scale, lse, (hipStream_t)stream);
+}
+int rald_op_rowdot_heads(const void* dO_bf16, const void* O_bf16, int64_t M, int32_t heads, int32_t nq, float* delta, void* stream) {
+    RALD_CHECK(dO_bf16 && O_bf16 && delta, "rald_op_rowdot_heads: null pointer");
+    return rowdot_heads((const bf16*)dO_bf16, (const bf16*)O_bf16, M, heads, nq, delta, (hipStream_t)stream);
+}
+int rald_op_attn_bwd_elem(const float* S, const float* dP, const float* lse, const float* delta, int64_t batch, int32_t R, int32_t Ccols,
+                          int64_t vbatch_stride, int32_t vstride, float scale, int32_t by_col, void* P_bf16, void* dS_bf16, void* stream) {
+    RALD_CHECK(S && dP && lse && delta && dS_bf16, "rald_op_attn_bwd_elem: null pointer");
+    return attn_bwd_elem(S, dP, lse, delta, batch, R, Ccols, vbatch_stride, vstride, scale, by_col, (bf16*)P_bf16, (bf16*)dS_bf16, (hipStream_t)stream);
+}
 int rald_op_gemm_mx8(const void* A8, const void* scaleA, int64_t lda, int64_t strideA, int64_t strideSA, const void* B8, const void* scaleB,
                      int64_t ldb, int64_t strideB, int64_t strideSB, void* C, int64_t ldc, int64_t strideC, const float* bias, int32_t M,
                      int32_t N, int32_t K, int32_t batch, float alpha, int32_t epilogue, void* stream) {

@@ -34,9 +34,9 @@ namespace rald {
 
 // ---- epilogue: lane owns row m = mb + 16i + fr, 4 consecutive columns n = nb + 16j + 4*fq + {0..3}
 template <int MT, int NT, int EPI>
-__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NT], const GemmArgs& a, int mb, int nb, int bz, int fr, int fq) {
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NT], const GemmArgs& a, int mb, int nb, int64_t coff, int fr, int fq) {
     if constexpr (EPI == EPI_GEGLU) {
-        bf16* C = reinterpret_cast<bf16*>(a.C) + (int64_t)bz * a.strideC;
+        bf16* C = reinterpret_cast<bf16*>(a.C) + coff;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int m = mb + i * 16 + fr;
@@ -68,15 +68,15 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[MT][NT], const GemmAr
                 if (a.bias) b = *reinterpret_cast<const float4*>(a.bias + n);
                 const float al = n < a.alpha_ncols ? a.alpha : 1.0f;
                 if constexpr (EPI == EPI_BF16) {
-                    bf16* C = reinterpret_cast<bf16*>(a.C) + (int64_t)bz * a.strideC;
+                    bf16* C = reinterpret_cast<bf16*>(a.C) + coff;
                     *reinterpret_cast<bf16x4*>(C + (int64_t)m * a.ldc + n) =
                         pack4(al * v[0] + b.x, al * v[1] + b.y, al * v[2] + b.z, al * v[3] + b.w);
                 } else if constexpr (EPI == EPI_F32) {
-                    float* C = reinterpret_cast<float*>(a.C) + (int64_t)bz * a.strideC;
+                    float* C = reinterpret_cast<float*>(a.C) + coff;
                     *reinterpret_cast<float4*>(C + (int64_t)m * a.ldc + n) =
                         make_float4(al * v[0] + b.x, al * v[1] + b.y, al * v[2] + b.z, al * v[3] + b.w);
                 } else {  // EPI_RESID
-                    float* C = reinterpret_cast<float*>(a.C) + (int64_t)bz * a.strideC;
+                    float* C = reinterpret_cast<float*>(a.C) + coff;
                     float4* p = reinterpret_cast<float4*>(C + (int64_t)m * a.ldc + n);
                     float4 r = *p;
                     *p = make_float4(r.x + v[0] + b.x, r.y + v[1] + b.y, r.z + v[2] + b.z, r.w + v[3] + b.w);
@@ -106,9 +106,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int bz = blockIdx.z;
-    const bf16* A = a.A + (int64_t)bz * a.strideA;
-    const bf16* B = a.B + (int64_t)bz * a.strideB;
+    int64_t oa, ob, coff;
+    gemm_batch_offsets(a, blockIdx.z, oa, ob, coff);
+    const bf16* A = a.A + oa;
+    const bf16* B = a.B + ob;
 
     // staging coordinates: thread -> (row within pass, 16-byte chunk)
     const int srow = tid >> 3, schunk = tid & 7;
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
         if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();
     }
-    gemm_epilogue<MT, NT, EPI>(acc, a, m0 + wm * (BM / 2), n0 + wn * (BN / 2), bz, fr, fq);
+    gemm_epilogue<MT, NT, EPI>(acc, a, m0 + wm * (BM / 2), n0 + wn * (BN / 2), coff, fr, fq);
 }
 
 // =================================================================================================
@@ -229,9 +230,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_glds_kernel(GemmArgs a) 
         tn = tile % ntn;
     }
     const int m0 = tm * BM, n0 = tn * BN;
-    const int bz = blockIdx.z;
-    const bf16* A = a.A + (int64_t)bz * a.strideA;
-    const bf16* B = a.B + (int64_t)bz * a.strideB;
+    int64_t oa, ob, coff;
+    gemm_batch_offsets(a, blockIdx.z, oa, ob, coff);
+    const bf16* A = a.A + oa;
+    const bf16* B = a.B + ob;
 
     // DMA source addresses.  Piece p of this wave covers tile rows 8*(wave + WAVES*p) .. +7; lane l
     // lands in LDS at piece_base + 16*l = (row r = l>>3, physical chunk l&7), which must hold the
@@ -355,13 +357,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_glds_kernel(GemmArgs a) 
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();             // every wave is done reading the staging buffers: reuse them as patches
     asm volatile("" ::: "memory");
-    gemm_epilogue_lds<MT, NT, EPI>(acc, a, m0 + wm * (BM / WM), n0 + wn * (BN / WN), bz, lane, smem + wave * 8704);
+    gemm_epilogue_lds<MT, NT, EPI>(acc, a, m0 + wm * (BM / WM), n0 + wn * (BN / WN), coff, lane, smem + wave * 8704);
 }
 
 // -------------------------------------------------------------------------------------------------
 template <int BM, int BN>
 static int launch_tile(const GemmArgs& a, int epi, hipStream_t st) {
-    dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), a.batch);
+    dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), a.batch * a.batch2);
     switch (epi) {
         case EPI_BF16:  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, EPI_BF16>), grid, dim3(256), 0, st, a); break;
         case EPI_F32:   hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, EPI_F32>), grid, dim3(256), 0, st, a); break;
@@ -384,7 +386,7 @@ static int launch_glds_epi(const GemmArgs& a, hipStream_t st) {
         RALD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), a.batch);
+    dim3 grid(cdiv(a.N, BN), cdiv(a.M, BM), a.batch * a.batch2);
     hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), smem, st, a);
     RALD_HIP(hipGetLastError());
     return 0;
@@ -412,7 +414,9 @@ int gemm_nt(const GemmArgs& a0, int epi, hipStream_t st) {
     return gemm_nt_impl(a, epi, st);
 }
 static int gemm_nt_impl(const GemmArgs& a, int epi, hipStream_t st) {
-    RALD_CHECK(a.M > 0 && a.N > 0 && a.K > 0 && a.batch > 0, "gemm: empty problem");
+    RALD_CHECK(a.M > 0 && a.N > 0 && a.K > 0 && a.batch > 0 && a.batch2 > 0, "gemm: empty problem");
+    const int64_t nbatch = (int64_t)a.batch * a.batch2;
+    RALD_CHECK(nbatch <= 65535, "gemm: batch * batch2 exceeds the grid z limit");
     RALD_CHECK(a.K % 64 == 0, "gemm: K must be a multiple of 64 (pad with zeros)");
     RALD_CHECK(a.N % 4 == 0, "gemm: N must be a multiple of 4");
     RALD_CHECK(a.lda % 8 == 0 && a.ldb % 8 == 0, "gemm: lda/ldb must be multiples of 8 elements (16-byte rows)");
@@ -432,16 +436,16 @@ static int gemm_nt_impl(const GemmArgs& a, int epi, hipStream_t st) {
     // 4 256x128 3 stages, 5 256x256 2 stages.
     int impl = -1;
     if (const char* e = getenv("RALD_GEMM_IMPL")) impl = atoi(e);
-    const int64_t wg128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) * a.batch;
+    const int64_t wg128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) * nbatch;
     if (wg128 < 192) {
         // small-M (batch-1) regime: too few tiles to hide memory latency behind other workgroups, so put
         // (up to) the whole K extent in flight at once: 64x64 tiles, 8-stage LDS-DMA ring (128 KB).
-        const int64_t wg64 = (int64_t)cdiv(a.M, 64) * cdiv(a.N, 64) * a.batch;
+        const int64_t wg64 = (int64_t)cdiv(a.M, 64) * cdiv(a.N, 64) * nbatch;
         if (impl == 0 || wg64 > 256) return launch_tile<64, 64>(a, epi, st);   // more than one tile per CU: 5 small workgroups/CU hide latency
         return launch_glds<64, 64, 2, 2, 8>(a, epi, st);
     }
     if (impl < 0) {
-        const int64_t wg256 = (int64_t)(a.M / 256) * (a.N / 256) * a.batch;
+        const int64_t wg256 = (int64_t)(a.M / 256) * (a.N / 256) * nbatch;
         if (a.M % 256 == 0 && a.N % 256 == 0 && wg256 >= 256) return launch_glds<256, 256, 4, 2, 2>(a, epi, st);
         return launch_glds<128, 128, 2, 2, 2>(a, epi, st);
     }

@@ -11,7 +11,7 @@ namespace rald {
 // patch (row stride padded by 16 B) and writes it back as whole rows, 16 B per lane: full 128-B
 // lines.  Wave-private, so no workgroup barrier; LDS ops of one wave execute in order.
 template <int MT, int NT, int EPI>
-__device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[MT][NT], const GemmArgs& a, int mb, int nb, int bz, int lane,
+__device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[MT][NT], const GemmArgs& a, int mb, int nb, int64_t coff, int lane,
                                                   unsigned char* patch) {
     const int fr = lane & 15, fq = lane >> 4;
     constexpr bool F32OUT = (EPI == EPI_F32 || EPI == EPI_RESID);
@@ -63,16 +63,16 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[MT][NT], const Ge
             const int c = oc0 + pc * EPP;
             if (m < a.M && c < ncols && !(a.ablate & 16)) {      // 16: diagnostics, no global stores
                 if constexpr (EPI == EPI_RESID) {
-                    float* C = reinterpret_cast<float*>(a.C) + (int64_t)bz * a.strideC + (int64_t)m * a.ldc + c;
+                    float* C = reinterpret_cast<float*>(a.C) + coff + (int64_t)m * a.ldc + c;
                     float4 x = *reinterpret_cast<float4*>(C);
                     const float4 d = *reinterpret_cast<const float4*>(&v);
                     x.x += d.x; x.y += d.y; x.z += d.z; x.w += d.w;
                     *reinterpret_cast<float4*>(C) = x;
                 } else if constexpr (EPI == EPI_F32) {
-                    float* C = reinterpret_cast<float*>(a.C) + (int64_t)bz * a.strideC + (int64_t)m * a.ldc + c;
+                    float* C = reinterpret_cast<float*>(a.C) + coff + (int64_t)m * a.ldc + c;
                     *reinterpret_cast<uint4*>(C) = v;
                 } else {
-                    bf16* C = reinterpret_cast<bf16*>(a.C) + (int64_t)bz * a.strideC + (int64_t)m * a.ldc + c;
+                    bf16* C = reinterpret_cast<bf16*>(a.C) + coff + (int64_t)m * a.ldc + c;
                     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                     if (c + 8 <= ncols) {
                         if (a.ablate & 64) __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(C));

@@ -54,8 +54,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mx8_kernel(Mx8Args a) {
         tn = tile % ntn;
     }
     const int m0 = tm * BM, n0 = tn * BN;
-    const int bz = blockIdx.z;
+    const int bz = blockIdx.z;                // (the MXFP8 engine has no inner batch: batch2 = 1)
     const GemmArgs& g = a.g;
+    const int64_t coff = (int64_t)bz * g.strideC;
     const unsigned char* A = a.A8 + (int64_t)bz * g.strideA;
     const unsigned char* B = a.B8 + (int64_t)bz * g.strideB;
     const unsigned char* SA = a.SA + (int64_t)bz * a.strideSA;
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mx8_kernel(Mx8Args a) {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();             // staging buffers become the epilogue patches
     asm volatile("" ::: "memory");
-    gemm_epilogue_lds<MT, NT, EPI>(acc, g, m0 + wm * (BM / WM), n0 + wn * (BN / WN), bz, lane, smem + wave * 8704);
+    gemm_epilogue_lds<MT, NT, EPI>(acc, g, m0 + wm * (BM / WM), n0 + wn * (BN / WN), coff, lane, smem + wave * 8704);
 }
 
 template <int BM, int BN, int WM, int WN, int EPI>

@@ -15,7 +15,19 @@ struct GemmArgs {
     float alpha;
     int alpha_ncols;                               // alpha applies to output columns n < alpha_ncols only (others use 1)
     int ablate;                                    // diagnostics only (RALD_GEMM_ABLATE): 1 = no DMA in the loop, 2 = no epilogue
+    // optional inner batch (attention heads): grid z = batch * batch2, blockIdx.z = b1 * batch2 + b2,
+    // operand offset = b1 * stride + b2 * stride2
+    int batch2 = 1;
+    int64_t strideA2 = 0, strideB2 = 0, strideC2 = 0;
 };
+#ifdef __HIPCC__
+__device__ __forceinline__ void gemm_batch_offsets(const GemmArgs& a, int bz, int64_t& oa, int64_t& ob, int64_t& oc) {
+    const int b1 = bz / a.batch2, b2 = bz - b1 * a.batch2;
+    oa = (int64_t)b1 * a.strideA + (int64_t)b2 * a.strideA2;
+    ob = (int64_t)b1 * a.strideB + (int64_t)b2 * a.strideB2;
+    oc = (int64_t)b1 * a.strideC + (int64_t)b2 * a.strideC2;
+}
+#endif
 int gemm_nt(const GemmArgs& a, int epi, hipStream_t st);
 inline GemmArgs gemm_args(const bf16* A, int64_t lda, const bf16* B, int64_t ldb, void* C, int64_t ldc,
                           const float* bias, int M, int N, int K) {
@@ -124,6 +136,23 @@ int quantize_mx8(const void* in, int in_is_bf16, int64_t ld_in, unsigned char* q
                  hipStream_t st);
 int layernorm_mod_mx8(const float* x, unsigned char* q, unsigned char* scales, int64_t rows, int D, const float* gam, const float* bet,
                       int64_t gstride, int rows_per_group, float add_one, float eps, hipStream_t st);
+
+// ---------------------------------------------------------------- train_kernels.hip (backward building blocks)
+struct TransposeArgs {
+    const void* in; int64_t ld_in, stride_in, stride_in2;     // [batch][batch2][rows][cols] f32 or bf16
+    bf16* out;      int64_t ld_out, stride_out, stride_out2;  // [batch][batch2][cols][rows] bf16
+    int rows, cols, batch, batch2;
+};
+int transpose_rows(const TransposeArgs& a, int in_is_bf16, hipStream_t st);
+int ln_mod_bwd(const float* x, const float* dh, const float* s, int64_t gstride, int rows_per_group, float add_one, float eps, int64_t rows,
+               int D, float* dx, float* ds, float* dt, hipStream_t st);
+int geglu_fwd(const bf16* u, bf16* hid, int64_t M, int I, hipStream_t st);
+int geglu_bwd(const bf16* u, const bf16* dhid, bf16* du, int64_t M, int I, hipStream_t st);
+int colsum(const void* X, int is_bf16, int64_t ld, int64_t M, int N, float* out, hipStream_t st);
+int row_lse(const float* S, int64_t rows, int cols, float scale, float* lse, hipStream_t st);
+int rowdot_heads(const bf16* dO, const bf16* O, int64_t M, int heads, int nq, float* delta, hipStream_t st);
+int attn_bwd_elem(const float* S, const float* dP, const float* lse, const float* delta, int64_t batch, int R, int Cc, int64_t vbatch_stride,
+                  int vstride, float scale, int by_col, bf16* P, bf16* dS, hipStream_t st);
 
 // ---------------------------------------------------------------- optim.hip
 int optim_grad_sumsq(const float* g, int64_t n, double* out, hipStream_t st);

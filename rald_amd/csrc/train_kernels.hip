@@ -1,0 +1,268 @@
+// Backward-pass building blocks of the denoiser's transformer block ("backward kernels
+// for K2-K5"): what autograd derives for models_radar_generation.py:35-169 (CrossAttention, GEGLU
+// FeedForward, AdaLayerNorm, BasicTransformerBlock), as explicit HIP kernels around the NT GEMM engine.
+//
+// GEMM shapes.  The engine contracts over the contiguous dimension of both operands (C = A.B^T), so
+//   dX = dY . W      ->  gemm_nt(A = dY [M,N],   B = W^T [K,N])          (weight transposed once per step)
+//   dW = dY^T . X    ->  gemm_nt(A = dY^T [N,M], B = X^T [K,M])          (activation transposes: transpose_rows)
+// Everything here is HBM-bound streaming work (transposes, LayerNorm / GEGLU / softmax backward, column
+// sums); the FLOPs stay in the MFMA GEMMs.
+#include "common.h"
+#include "kernels.h"
+
+namespace rald {
+
+// ---- batched 2-D transpose with cast to bf16: in [rows][cols] (f32 or bf16) -> out [cols][rows] bf16 -------
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_rows_kernel(TransposeArgs a) {
+    __shared__ float tile[64][65];
+    const int b1 = blockIdx.z / a.batch2, b2 = blockIdx.z - b1 * a.batch2;
+    const T* in = reinterpret_cast<const T*>(a.in) + (int64_t)b1 * a.stride_in + (int64_t)b2 * a.stride_in2;
+    bf16* out = a.out + (int64_t)b1 * a.stride_out + (int64_t)b2 * a.stride_out2;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < a.rows && c < a.cols) ? (float)in[(int64_t)r * a.ld_in + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < a.cols && r < a.rows) out[(int64_t)c * a.ld_out + r] = (bf16)tile[tx][i];
+    }
+}
+
+int transpose_rows(const TransposeArgs& a, int in_is_bf16, hipStream_t st) {
+    RALD_CHECK(a.rows > 0 && a.cols > 0 && a.batch > 0 && a.batch2 > 0 && a.in && a.out, "transpose_rows: bad arguments");
+    RALD_CHECK((int64_t)a.batch * a.batch2 <= 65535, "transpose_rows: too many batches");
+    dim3 grid(cdiv(a.cols, 64), cdiv(a.rows, 64), a.batch * a.batch2);
+    if (in_is_bf16) hipLaunchKernelGGL(transpose_rows_kernel<bf16>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(transpose_rows_kernel<float>, grid, dim3(256), 0, st, a);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- AdaLayerNorm / LayerNorm backward, D = 512 -------------------------------------------------------------
+// forward: h = xhat * (add_one + s[g]) + t[g], xhat = (x - mean) * rstd.  Given dh:
+//   dx += rstd * (gh - mean(gh) - xhat * mean(gh * xhat)),  gh = dh * (add_one + s[g])
+//   ds[g] += sum_rows dh * xhat,   dt[g] += sum_rows dh
+// One wave per row (the row stays in registers), 16 rows per workgroup (all in one group when
+// rows_per_group % 16 == 0), column sums reduced through LDS, one atomicAdd per column per workgroup.
+__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dh, const float* __restrict__ s,
+                                                         int64_t gstride, int rows_per_group, float add_one, float eps, int64_t rows,
+                                                         float* __restrict__ dx, float* __restrict__ ds, float* __restrict__ dt) {
+    constexpr int D = 512, RPW = 4;                          // 4 waves x 4 rows
+    __shared__ float red[2][4][D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float as[8], at[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) as[i] = at[i] = 0.f;
+    const int64_t row0 = (int64_t)blockIdx.x * (4 * RPW);
+    const int64_t grp = row0 / rows_per_group;               // host guarantees rows_per_group % 16 == 0
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int64_t row = row0 + wave * RPW + rr;
+        if (row >= rows) break;
+        const float4 a = *reinterpret_cast<const float4*>(x + row * D + lane * 8), b = *reinterpret_cast<const float4*>(x + row * D + lane * 8 + 4);
+        const float4 c = *reinterpret_cast<const float4*>(dh + row * D + lane * 8), d = *reinterpret_cast<const float4*>(dh + row * D + lane * 8 + 4);
+        float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        const float g[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sum += v[i];
+        const float mean = wave_sum(sum) * (1.0f / D);
+        float var = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[i] -= mean; var += v[i] * v[i]; }
+        const float rstd = rsqrtf(wave_sum(var) * (1.0f / D) + eps);
+        const float* sp = s + grp * gstride + lane * 8;
+        float gh[8], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            v[i] *= rstd;                                     // xhat
+            gh[i] = g[i] * (add_one + sp[i]);
+            m1 += gh[i];
+            m2 += gh[i] * v[i];
+            as[i] += g[i] * v[i];
+            at[i] += g[i];
+        }
+        m1 = wave_sum(m1) * (1.0f / D);
+        m2 = wave_sum(m2) * (1.0f / D);
+        float* o = dx + row * D + lane * 8;
+        float4 o0 = *reinterpret_cast<float4*>(o), o1 = *reinterpret_cast<float4*>(o + 4);
+        o0.x += rstd * (gh[0] - m1 - v[0] * m2); o0.y += rstd * (gh[1] - m1 - v[1] * m2);
+        o0.z += rstd * (gh[2] - m1 - v[2] * m2); o0.w += rstd * (gh[3] - m1 - v[3] * m2);
+        o1.x += rstd * (gh[4] - m1 - v[4] * m2); o1.y += rstd * (gh[5] - m1 - v[5] * m2);
+        o1.z += rstd * (gh[6] - m1 - v[6] * m2); o1.w += rstd * (gh[7] - m1 - v[7] * m2);
+        *reinterpret_cast<float4*>(o) = o0;
+        *reinterpret_cast<float4*>(o + 4) = o1;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { red[0][wave][lane * 8 + i] = as[i]; red[1][wave][lane * 8 + i] = at[i]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * D; c += 256) {
+        const int which = c / D, col = c % D;
+        const float v = red[which][0][col] + red[which][1][col] + red[which][2][col] + red[which][3][col];
+        atomicAdd((which ? dt : ds) + grp * gstride + col, v);
+    }
+}
+
+int ln_mod_bwd(const float* x, const float* dh, const float* s, int64_t gstride, int rows_per_group, float add_one, float eps, int64_t rows,
+               int D, float* dx, float* ds, float* dt, hipStream_t st) {
+    RALD_CHECK(D == 512, "ln_mod_bwd: D must be 512");
+    RALD_CHECK(rows > 0 && rows_per_group > 0 && (rows_per_group % 16 == 0 || rows_per_group >= rows), "ln_mod_bwd: rows_per_group must be a multiple of 16");
+    hipLaunchKernelGGL(ln_mod_bwd_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, x, dh, s, gstride, rows_per_group, add_one, eps, rows,
+                       dx, ds, dt);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- GEGLU (models_radar_generation.py:88-95), natural layout: u [M][2I] = [a | g], hid = a * gelu_erf(g) ---------
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const bf16* __restrict__ u, bf16* __restrict__ hid, int64_t M, int I) {
+    const int64_t idx = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (idx >= M * I) return;
+    const int64_t m = idx / I;
+    const int c = (int)(idx % I);
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(u + m * 2 * I + c), g = *reinterpret_cast<const bf16x8*>(u + m * 2 * I + I + c);
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (bf16)((float)a[i] * gelu_erf((float)g[i]));
+    *reinterpret_cast<bf16x8*>(hid + m * I + c) = o;
+}
+
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16* __restrict__ u, const bf16* __restrict__ dhid, bf16* __restrict__ du, int64_t M, int I) {
+    const int64_t idx = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (idx >= M * I) return;
+    const int64_t m = idx / I;
+    const int c = (int)(idx % I);
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(u + m * 2 * I + c), g = *reinterpret_cast<const bf16x8*>(u + m * 2 * I + I + c);
+    const bf16x8 d = *reinterpret_cast<const bf16x8*>(dhid + m * I + c);
+    bf16x8 da, dg;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float gv = (float)g[i], dv = (float)d[i];
+        const float cdf = 0.5f * (1.0f + erff(gv * 0.70710678118654752f));
+        const float pdf = 0.3989422804014327f * __expf(-0.5f * gv * gv);
+        da[i] = (bf16)(dv * gv * cdf);                        // d/da (a * gelu(g))
+        dg[i] = (bf16)(dv * (float)a[i] * (cdf + gv * pdf));  // gelu'(g) = Phi(g) + g * phi(g)
+    }
+    *reinterpret_cast<bf16x8*>(du + m * 2 * I + c) = da;
+    *reinterpret_cast<bf16x8*>(du + m * 2 * I + I + c) = dg;
+}
+
+int geglu_fwd(const bf16* u, bf16* hid, int64_t M, int I, hipStream_t st) {
+    RALD_CHECK(M > 0 && I > 0 && I % 8 == 0, "geglu_fwd: inner width must be a multiple of 8");
+    hipLaunchKernelGGL(geglu_fwd_kernel, dim3((unsigned)((M * I / 8 + 255) / 256)), dim3(256), 0, st, u, hid, M, I);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+int geglu_bwd(const bf16* u, const bf16* dhid, bf16* du, int64_t M, int I, hipStream_t st) {
+    RALD_CHECK(M > 0 && I > 0 && I % 8 == 0, "geglu_bwd: inner width must be a multiple of 8");
+    hipLaunchKernelGGL(geglu_bwd_kernel, dim3((unsigned)((M * I / 8 + 255) / 256)), dim3(256), 0, st, u, dhid, du, M, I);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- bias gradients: out[n] += sum_m X[m][n] (X f32 or bf16) ----------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int64_t ld, int64_t M, int N, int rows_per_block, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += (float)X[r * ld + c];
+    atomicAdd(out + c, s);
+}
+int colsum(const void* X, int is_bf16, int64_t ld, int64_t M, int N, float* out, hipStream_t st) {
+    RALD_CHECK(M > 0 && N > 0 && X && out, "colsum: bad arguments");
+    const int rpb = 128;
+    dim3 grid(cdiv(N, 256), (unsigned)((M + rpb - 1) / rpb));
+    if (is_bf16) hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)X, ld, M, N, rpb, out);
+    else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)X, ld, M, N, rpb, out);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- attention backward, element-wise parts (the products are batched NT GEMMs) -----------------------------
+// lse[r] = log sum_c exp(scale * S[r][c])  (one wave per row)
+__global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ S, int64_t rows, int cols, float scale, float* __restrict__ lse) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* p = S + row * cols;
+    float mx = -INFINITY;
+    for (int c = lane; c < cols; c += 64) mx = fmaxf(mx, p[c] * scale);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int c = lane; c < cols; c += 64) sum += __expf(p[c] * scale - mx);
+    sum = wave_sum(sum);
+    if (lane == 0) lse[row] = mx + __logf(sum);
+}
+// delta[b][h][q] = sum_d dO[m][h*64 + d] * O[m][h*64 + d], m = b*nq + q  (the [batch*heads][nq] layout of lse)
+__global__ __launch_bounds__(256) void rowdot_heads_kernel(const bf16* __restrict__ dO, const bf16* __restrict__ O, int64_t M, int heads, int nq,
+                                                           float* __restrict__ delta) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;      // (m, h, octet)
+    const int64_t mh = idx >> 3;
+    if (mh >= M * heads) return;
+    const int oct = (int)(idx & 7);
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(dO + mh * 64 + oct * 8), b = *reinterpret_cast<const bf16x8*>(O + mh * 64 + oct * 8);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += (float)a[i] * (float)b[i];
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    if (oct == 0) {
+        const int64_t m = mh / heads;
+        const int h = (int)(mh - m * heads);
+        const int64_t bb = m / nq;
+        delta[(bb * heads + h) * nq + (m - bb * nq)] = s;
+    }
+}
+// P = exp(scale*S - lse[i]), dS = P * (dP - delta[i]) * scale, i = row (by_col = 0) or column (by_col = 1: the
+// transposed orientation S^T = K.Q^T, whose softmax normaliser belongs to the COLUMN's query).
+// S, dP: [batch][R][C] f32; lse/delta: [batch][R or C] with element stride `vstride`.
+__global__ __launch_bounds__(256) void attn_bwd_elem_kernel(const float* __restrict__ S, const float* __restrict__ dP, const float* __restrict__ lse,
+                                                            const float* __restrict__ delta, int R, int Cc, int64_t vbatch_stride, int vstride,
+                                                            float scale, int by_col, bf16* __restrict__ P, bf16* __restrict__ dS, int64_t total) {
+    const int64_t idx = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (idx >= total) return;
+    const int64_t per = (int64_t)R * Cc;
+    const int64_t b = idx / per;
+    const int64_t rem = idx - b * per;
+    const int r = (int)(rem / Cc), c = (int)(rem % Cc);
+    const float4 s = *reinterpret_cast<const float4*>(S + idx), d = *reinterpret_cast<const float4*>(dP + idx);
+    const float sv[4] = {s.x, s.y, s.z, s.w}, dv[4] = {d.x, d.y, d.z, d.w};
+    bf16x4 po, so;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t vi = b * vbatch_stride + (int64_t)(by_col ? c + i : r) * vstride;
+        const float p = __expf(sv[i] * scale - lse[vi]);
+        po[i] = (bf16)p;
+        so[i] = (bf16)(p * (dv[i] - delta[vi]) * scale);
+    }
+    if (P) *reinterpret_cast<bf16x4*>(P + idx) = po;
+    *reinterpret_cast<bf16x4*>(dS + idx) = so;
+}
+
+int row_lse(const float* S, int64_t rows, int cols, float scale, float* lse, hipStream_t st) {
+    RALD_CHECK(rows > 0 && cols > 0, "row_lse: empty");
+    hipLaunchKernelGGL(row_lse_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, S, rows, cols, scale, lse);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+int rowdot_heads(const bf16* dO, const bf16* O, int64_t M, int heads, int nq, float* delta, hipStream_t st) {
+    RALD_CHECK(M > 0 && heads > 0 && nq > 0 && M % nq == 0, "rowdot_heads: M must be a multiple of nq");
+    hipLaunchKernelGGL(rowdot_heads_kernel, dim3((unsigned)((M * heads * 8 + 255) / 256)), dim3(256), 0, st, dO, O, M, heads, nq, delta);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+int attn_bwd_elem(const float* S, const float* dP, const float* lse, const float* delta, int64_t batch, int R, int Cc, int64_t vbatch_stride,
+                  int vstride, float scale, int by_col, bf16* P, bf16* dS, hipStream_t st) {
+    RALD_CHECK(batch > 0 && R > 0 && Cc > 0 && Cc % 4 == 0, "attn_bwd_elem: the column count must be a multiple of 4");
+    const int64_t total = batch * R * Cc;
+    hipLaunchKernelGGL(attn_bwd_elem_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, S, dP, lse, delta, R, Cc, vbatch_stride,
+                       vstride, scale, by_col, P, dS, total);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace rald

@@ -1,0 +1,123 @@
+"""Backward pass of one BasicTransformerBlock on the HIP kernels against autograd
+of the CPU oracle (oracle/rald_oracle.transformer_block, itself pinned to the reference's block by G1).
+Kernel-level checks against plain torch autograd first, then the whole block: forward output, input
+gradient, every weight / bias gradient, the AdaLN-linear gradients (through dmod) and the condition-token
+gradient.  Tolerance: bf16 MFMA operands with fp32 accumulation in both directions -> rel-L2 <= 3e-2 per
+gradient tensor (stated per assert)."""
+import pytest
+import torch
+
+from conftest import rel_l2
+from rald_amd import synth, weights
+
+pytestmark = pytest.mark.gpu
+
+
+def test_backward_kernels_vs_torch_autograd():
+    from rald_amd import train_ops as TO
+    # transpose (f32 and bf16 in, batched with inner stride)
+    x = synth.normal([3, 100, 192], 500).cuda()
+    t = TO.transpose(x, 100, 64, 192, batch=3, stride_in=100 * 192, batch2=3, stride_in2=64)
+    assert t.shape == (3, 3, 64, 100)
+    want = x.reshape(3, 100, 3, 64).permute(0, 2, 3, 1).bfloat16()
+    assert torch.equal(t, want)
+    assert torch.equal(TO.T2(x[0].bfloat16()), x[0].bfloat16().T.contiguous())
+    # LayerNorm-mod backward
+    B, NL, D = 3, 48, 512
+    xx = (synth.normal([B * NL, D], 501) * 2 + 0.3).requires_grad_()
+    s, sh = (synth.normal([B, D], 502) * 0.2).requires_grad_(), (synth.normal([B, D], 503) * 0.2).requires_grad_()
+    dh = synth.normal([B * NL, D], 504)
+    h = torch.nn.functional.layer_norm(xx, (D,)).reshape(B, NL, D) * (1 + s[:, None]) + sh[:, None]
+    h.backward(dh.reshape(B, NL, D))
+    mod = torch.cat([s.detach(), sh.detach()], 1).cuda().contiguous()
+    dx = torch.ones(B * NL, D, device="cuda")
+    dmod = torch.zeros_like(mod)
+    TO.ln_mod_bwd(xx.detach().cuda(), dh.cuda(), mod[:, :D], 2 * D, NL, 1.0, dx, dmod[:, :D], dmod[:, D:])
+    assert rel_l2(dx.cpu() - 1, xx.grad) < 1e-5
+    assert rel_l2(dmod[:, :D].cpu(), s.grad) < 1e-5 and rel_l2(dmod[:, D:].cpu(), sh.grad) < 1e-5
+    # GEGLU forward / backward (bf16 storage: compare against fp32 math on the same bf16 inputs)
+    u = (synth.normal([70, 256], 505) * 1.5).bfloat16()
+    dhid = synth.normal([70, 128], 506).bfloat16()
+    uf = u.float().requires_grad_()
+    a, g = uf.chunk(2, dim=-1)
+    hid = a * torch.nn.functional.gelu(g)
+    hid.backward(dhid.float())
+    assert rel_l2(TO.geglu_fwd(u.cuda()).float().cpu(), hid.detach()) < 4e-3
+    assert rel_l2(TO.geglu_bwd(u.cuda(), dhid.cuda()).float().cpu(), uf.grad) < 4e-3
+    # column sums
+    y = synth.normal([1000, 300], 507)
+    out = torch.ones(300, device="cuda")
+    TO.colsum(y.cuda(), out)
+    assert rel_l2(out.cpu() - 1, y.sum(0)) < 1e-5
+    out.zero_()
+    TO.colsum(y.bfloat16().cuda(), out)
+    assert rel_l2(out.cpu(), y.bfloat16().float().sum(0)) < 1e-5
+
+
+def test_attention_backward_vs_autograd():
+    from rald_amd import train_ops as TO
+    for (Bn, nq, nk) in ((2, 128, 128), (2, 192, 64)):
+        H, D = 8, 512
+        mk = lambda shape, seed: (synth.normal(shape, seed) * 0.7).bfloat16()
+        q, k, v, dO = mk([Bn * nq, D], 510), mk([Bn * nk, D], 511), mk([Bn * nk, D], 512), mk([Bn * nq, D], 513)
+        qf, kf, vf = (t.float().requires_grad_() for t in (q, k, v))
+        heads = lambda t, n: t.reshape(Bn, n, H, 64).transpose(1, 2)
+        P = torch.softmax(heads(qf, nq) @ heads(kf, nk).transpose(-1, -2) / 8.0, dim=-1)
+        O = (P @ heads(vf, nk)).transpose(1, 2).reshape(Bn * nq, D)
+        O.backward(dO.float())
+        dq, dk, dv = (torch.empty_like(t, device="cuda") for t in (q, k, v))
+        TO.attention_backward(q.cuda(), D, k.cuda(), D, v.cuda(), D, O.detach().bfloat16().cuda(), dO.cuda(), Bn, H, nq, nk, dq, D, dk, D, dv, D)
+        for name, got, want in (("dq", dq, qf.grad), ("dk", dk, kf.grad), ("dv", dv, vf.grad)):
+            err = rel_l2(got.float().cpu(), want)
+            print(f"attention backward nq={nq} nk={nk} {name}: rel_l2 {err:.2e}")
+            assert err < 1.5e-2
+
+
+def test_block_forward_backward_vs_oracle_autograd():
+    from oracle import rald_oracle as O
+    from rald_amd import train_ops as TO
+    Bn, NL, T, D = 2, 512, 64, 512
+    sd = weights.make_state_dict(weights.dit_spec(depth=2), 0)
+    p = "model.transformer_blocks.1."
+    names = [k for k in sd if k.startswith(p)]
+    leaf = {k: sd[k].clone().requires_grad_() for k in names}
+    x0 = synth.normal([Bn, NL, D], 520).requires_grad_()
+    t_emb = (synth.normal([Bn, 1, D], 521) * 0.5).requires_grad_()
+    cond = synth.cond_tokens(Bn, T, D, seed=522).requires_grad_()
+    dout = synth.normal([Bn, NL, D], 523)
+    y = O.transformer_block(leaf, p, x0, t_emb, cond)
+    y.backward(dout)
+
+    W = TO.prepare_block_weights(sd, p, "cuda")
+    mod = torch.stack([t_emb.detach()[:, 0] @ sd[p + f"norm{j}.linear.weight"].T + sd[p + f"norm{j}.linear.bias"] for j in (1, 2, 3)], 1)
+    x = x0.detach().reshape(Bn * NL, D).cuda().contiguous()
+    sv = TO.block_forward(W, x, mod.cuda().contiguous(), cond.detach().reshape(Bn * T, D).bfloat16().cuda(), Bn, NL)
+    err = rel_l2(x.cpu().reshape(Bn, NL, D), y.detach())
+    print("block forward rel_l2", err)
+    assert err < 1e-2
+    dx = dout.reshape(Bn * NL, D).cuda().contiguous()
+    G, dmod, dcond = TO.block_backward(W, sv, dx)
+    torch.cuda.synchronize()
+    checks = [("dx", dx.cpu().reshape(Bn, NL, D), x0.grad), ("dcond", dcond.cpu().reshape(Bn, T, D), cond.grad)]
+    wq = torch.cat([leaf[p + f"attn1.to_{n}.weight"].grad for n in "qkv"], 0)
+    checks += [("attn1.qkv", G["qkv"].cpu(), wq), ("attn1.to_out.w", G["o"].cpu(), leaf[p + "attn1.to_out.0.weight"].grad),
+               ("attn1.to_out.b", G["bo"].cpu(), leaf[p + "attn1.to_out.0.bias"].grad),
+               ("attn2.to_q", G["q2"].cpu(), leaf[p + "attn2.to_q.weight"].grad), ("attn2.to_k", G["k2"].cpu(), leaf[p + "attn2.to_k.weight"].grad),
+               ("attn2.to_v", G["v2"].cpu(), leaf[p + "attn2.to_v.weight"].grad), ("attn2.to_out.w", G["o2"].cpu(), leaf[p + "attn2.to_out.0.weight"].grad),
+               ("attn2.to_out.b", G["bo2"].cpu(), leaf[p + "attn2.to_out.0.bias"].grad),
+               ("ff.proj.w", G["w1"].cpu(), leaf[p + "ff.net.0.proj.weight"].grad), ("ff.proj.b", G["b1"].cpu(), leaf[p + "ff.net.0.proj.bias"].grad),
+               ("ff.out.w", G["w2"].cpu(), leaf[p + "ff.net.2.weight"].grad), ("ff.out.b", G["b2"].cpu(), leaf[p + "ff.net.2.bias"].grad)]
+    dm = dmod.cpu()
+    te = t_emb.detach()[:, 0]
+    for j in (1, 2, 3):
+        checks += [(f"norm{j}.linear.w", dm[:, j - 1].T @ te, leaf[p + f"norm{j}.linear.weight"].grad),
+                   (f"norm{j}.linear.b", dm[:, j - 1].sum(0), leaf[p + f"norm{j}.linear.bias"].grad)]
+    dte = sum(dm[:, j - 1] @ sd[p + f"norm{j}.linear.weight"] for j in (1, 2, 3))
+    checks.append(("t_emb", dte, t_emb.grad[:, 0]))
+    worst = 0.0
+    for name, got, want in checks:
+        e = rel_l2(got, want)
+        worst = max(worst, e)
+        print(f"  grad {name:16s} rel_l2 {e:.2e}")
+        assert e < 3e-2, name
+    print("worst gradient rel_l2", worst)
