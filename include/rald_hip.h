@@ -256,6 +256,18 @@ int rald_op_row_lse(const float* S, int64_t rows, int32_t cols, float scale, flo
 int rald_op_rowdot_heads(const void* dO_bf16, const void* O_bf16, int64_t M, int32_t heads, int32_t nq, float* delta, void* stream);
 int rald_op_attn_bwd_elem(const float* S, const float* dP, const float* lse, const float* delta, int64_t batch, int32_t R, int32_t Ccols,
                           int64_t vbatch_stride, int32_t vstride, float scale, int32_t by_col, void* P_bf16, void* dS_bf16, void* stream);
+/* thin fp32 products of the training step (timestep MLP, AdaLN linears, proj_in/out and their gradients):
+ * C[m][n] += alpha * sum_k A(m,k)*B(n,k); A(m,k) = A[m*lda+k] or (trans_a) A[k*lda+m]; B(n,k) = B[n*ldb+k] or (trans_b) B[k*ldb+n] */
+int rald_op_sgemm_acc(const float* A, int64_t lda, int32_t trans_a, const float* B, int64_t ldb, int32_t trans_b, float* C, int64_t ldc, int32_t M,
+                      int32_t N, int32_t K, float alpha, void* stream);
+int rald_op_silu_fwd(const float* x, float* y, int64_t n, void* stream);
+int rald_op_silu_bwd(const float* x_pre, const float* dy, float* dx, int64_t n, void* stream);
+/* PositionalEmbedding :20-33: out [n, channels] = cat[cos, sin](outer(t, freqs)) */
+int rald_op_posemb(const float* t, float* out, int32_t n, int32_t channels, void* stream);
+/* EDMLoss :283-295 over EDMPrecond.forward's output mix :422-430: coef3[b] = {c_skip, c_out, weight};
+ * D = c_skip*x_noised + c_out*F; *loss = mean(weight*(D - y)^2) (device double); dF = dloss/dF; D_out optional */
+int rald_op_edm_loss_grad(const float* F, const float* x_noised, const float* y, const float* coef3, int64_t per_sample, int64_t total, float* dF,
+                          float* D_out, double* loss, void* stream);
 /* MXFP8 (OCP microscaling: e4m3 elements + one e8m0 scale per 32 consecutive K elements of a row), the
  * "fp8 MFMA QKV/proj path" of BASELINE config #5.  C = alpha * A . B^T + bias on
  * v_mfma_scale_f32_16x16x128_f8f6f4; epilogue 0 = bf16, 1 = f32, 2 = f32 residual accumulate.  K % 128 == 0;

@@ -95,6 +95,11 @@ SIGNATURES = {
     "rald_op_rowdot_heads": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p, c_void_p]),
     "rald_op_attn_bwd_elem": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_int, c_i64, c_int, c_float, c_int, c_void_p,
                                       c_void_p, c_void_p]),
+    "rald_op_sgemm_acc": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_i64, c_int, c_void_p, c_i64, c_int, c_int, c_int, c_float, c_void_p]),
+    "rald_op_silu_fwd": (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
+    "rald_op_silu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
+    "rald_op_posemb": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "rald_op_edm_loss_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rald_op_gemm_mx8": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_void_p, c_i64, c_i64,
                                  c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "rald_op_quantize_mx8": (c_int, [c_void_p, c_int, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p]),

@@ -276,6 +276,21 @@ int rald_op_attn_bwd_elem(const float* S, const float* dP, const float* lse, con
     RALD_CHECK(S && dP && lse && delta && dS_bf16, "rald_op_attn_bwd_elem: null pointer");
     return attn_bwd_elem(S, dP, lse, delta, batch, R, Ccols, vbatch_stride, vstride, scale, by_col, (bf16*)P_bf16, (bf16*)dS_bf16, (hipStream_t)stream);
 }
+int rald_op_sgemm_acc(const float* A, int64_t lda, int32_t trans_a, const float* B, int64_t ldb, int32_t trans_b, float* C, int64_t ldc, int32_t M,
+                      int32_t N, int32_t K, float alpha, void* stream) {
+    return sgemm_acc(A, lda, trans_a, B, ldb, trans_b, C, ldc, M, N, K, alpha, (hipStream_t)stream);
+}
+int rald_op_silu_fwd(const float* x, float* y, int64_t n, void* stream) { return silu_fwd(x, y, n, (hipStream_t)stream); }
+int rald_op_silu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream) { return silu_bwd(x, dy, dx, n, (hipStream_t)stream); }
+int rald_op_posemb(const float* t, float* out, int32_t n, int32_t channels, void* stream) {
+    RALD_CHECK(t && out && n > 0, "rald_op_posemb: bad arguments");
+    return positional_embedding(t, out, n, channels, (hipStream_t)stream);
+}
+int rald_op_edm_loss_grad(const float* F, const float* x_noised, const float* y, const float* coef3, int64_t per_sample, int64_t total, float* dF,
+                          float* D_out, double* loss, void* stream) {
+    RALD_CHECK(F && x_noised && y && coef3 && dF && loss, "rald_op_edm_loss_grad: null pointer");
+    return edm_loss_grad(F, x_noised, y, coef3, per_sample, total, dF, D_out, loss, (hipStream_t)stream);
+}
 int rald_op_gemm_mx8(const void* A8, const void* scaleA, int64_t lda, int64_t strideA, int64_t strideSA, const void* B8, const void* scaleB,
                      int64_t ldb, int64_t strideB, int64_t strideSB, void* C, int64_t ldc, int64_t strideC, const float* bias, int32_t M,
                      int32_t N, int32_t K, int32_t batch, float alpha, int32_t epilogue, void* stream) {

@@ -154,6 +154,13 @@ int rowdot_heads(const bf16* dO, const bf16* O, int64_t M, int heads, int nq, fl
 int attn_bwd_elem(const float* S, const float* dP, const float* lse, const float* delta, int64_t batch, int R, int Cc, int64_t vbatch_stride,
                   int vstride, float scale, int by_col, bf16* P, bf16* dS, hipStream_t st);
 
+int sgemm_acc(const float* A, int64_t lda, int trans_a, const float* B, int64_t ldb, int trans_b, float* Cm, int64_t ldc, int M, int N, int K,
+              float alpha, hipStream_t st);
+int silu_fwd(const float* x, float* y, int64_t n, hipStream_t st);
+int silu_bwd(const float* x, const float* dy, float* dx, int64_t n, hipStream_t st);
+int edm_loss_grad(const float* F, const float* xn, const float* y, const float* coef, int64_t per_sample, int64_t total, float* dF, float* D_out,
+                  double* loss, hipStream_t st);
+
 // ---------------------------------------------------------------- optim.hip
 int optim_grad_sumsq(const float* g, int64_t n, double* out, hipStream_t st);
 int optim_clip_coef(const double* sumsq, float pre_scale, float max_norm, float* out2, hipStream_t st);

@@ -266,3 +266,142 @@ int attn_bwd_elem(const float* S, const float* dP, const float* lse, const float
 }
 
 }  // namespace rald
+
+// =================================================================================================
+// Small fp32 pieces of the training step: the timestep-embedding MLP, the 72 AdaLN linears, proj_in /
+// proj_out and their gradients have one dimension of 32..512 or a contraction over the batch - far too thin
+// for the MFMA tile engine.  One generic FMA kernel covers them:
+//   C[m][n] += alpha * sum_k A(m,k) * B(n,k),  A(m,k) = A[m*lda + k] or (trans_a) A[k*lda + m],
+//                                              B(n,k) = B[n*ldb + k] or (trans_b) B[k*ldb + n]
+// 64x64 tiles, 16-deep k chunks through LDS, 4x4 outputs per thread; long contractions are split over
+// grid.z and combined with fp32 atomics.
+// =================================================================================================
+namespace rald {
+
+__global__ __launch_bounds__(256) void sgemm_acc_kernel(const float* __restrict__ A, int64_t lda, int trans_a, const float* __restrict__ B, int64_t ldb,
+                                                        int trans_b, float* __restrict__ Cm, int64_t ldc, int M, int N, int K, int k_chunk, float alpha,
+                                                        int use_atomics) {
+    __shared__ float sA[16][65], sB[16][65];
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int k_lo = blockIdx.z * k_chunk, k_hi = k_lo + k_chunk < K ? k_lo + k_chunk : K;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
+        for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+            int kk, mm;
+            if (trans_a) { mm = e & 63; kk = e >> 6; } else { kk = e & 15; mm = e >> 4; }     // contiguous index fastest
+            const int m = m0 + mm, k = k0 + kk;
+            sA[kk][mm] = (m < M && k < k_hi) ? (trans_a ? A[(int64_t)k * lda + m] : A[(int64_t)m * lda + k]) : 0.f;
+            int nn;
+            if (trans_b) { nn = e & 63; kk = e >> 6; } else { kk = e & 15; nn = e >> 4; }
+            const int n = n0 + nn, kb = k0 + kk;
+            sB[kk][nn] = (n < N && kb < k_hi) ? (trans_b ? B[(int64_t)kb * ldb + n] : B[(int64_t)n * ldb + kb]) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = sA[kk][ty * 4 + i]; b[i] = sB[kk][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty * 4 + i;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + tx * 4 + j;
+            if (n >= N) continue;
+            float* c = Cm + (int64_t)m * ldc + n;
+            if (use_atomics) atomicAdd(c, alpha * acc[i][j]);
+            else *c += alpha * acc[i][j];
+        }
+    }
+}
+
+int sgemm_acc(const float* A, int64_t lda, int trans_a, const float* B, int64_t ldb, int trans_b, float* Cm, int64_t ldc, int M, int N, int K,
+              float alpha, hipStream_t st) {
+    RALD_CHECK(M > 0 && N > 0 && K > 0 && A && B && Cm, "sgemm_acc: bad arguments");
+    const int tiles = cdiv(M, 64) * cdiv(N, 64);
+    int splits = 1;
+    if (tiles < 256 && K > 256) {                      // too few tiles to fill the chip: split the contraction
+        splits = cdiv(512, tiles);
+        const int max_splits = cdiv(K, 128);
+        if (splits > max_splits) splits = max_splits;
+        if (splits > 1024) splits = 1024;
+    }
+    const int k_chunk = cdiv(cdiv(K, splits), 16) * 16;
+    splits = cdiv(K, k_chunk);
+    dim3 grid(cdiv(N, 64), cdiv(M, 64), splits);
+    hipLaunchKernelGGL(sgemm_acc_kernel, grid, dim3(256), 0, st, A, lda, trans_a, B, ldb, trans_b, Cm, ldc, M, N, K, k_chunk, alpha, splits > 1 ? 1 : 0);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+// silu(x) = x * sigmoid(x)  (models_radar_generation.py:217-219)
+__global__ void silu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const float v = x[i]; y[i] = v / (1.0f + __expf(-v)); }
+}
+__global__ void silu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float v = x[i], s = 1.0f / (1.0f + __expf(-v));
+        dx[i] = dy[i] * s * (1.0f + v * (1.0f - s));
+    }
+}
+int silu_fwd(const float* x, float* y, int64_t n, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(silu_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+int silu_bwd(const float* x, const float* dy, float* dx, int64_t n, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, dy, dx, n);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+// EDMLoss (models_radar_generation.py:283-295) + EDMPrecond.forward's output mix (:422-430), per element:
+//   D = c_skip*xn + c_out*F;  loss += w*(D - y)^2 / numel;  dF = 2*w*c_out*(D - y) / numel
+// coef[b] = {c_skip, c_out, w}.  Also writes D (optional).
+__global__ __launch_bounds__(256) void edm_loss_kernel(const float* __restrict__ F, const float* __restrict__ xn, const float* __restrict__ y,
+                                                       const float* __restrict__ coef, int64_t per_sample, int64_t total, float* __restrict__ dF,
+                                                       float* __restrict__ D_out, double* __restrict__ loss) {
+    __shared__ double sh[4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double part = 0.0;
+    if (i < total) {
+        const float* c = coef + (i / per_sample) * 3;
+        const float d = c[0] * xn[i] + c[1] * F[i];
+        const float r = d - y[i];
+        part = (double)(c[2] * r * r);
+        dF[i] = 2.0f * c[2] * c[1] * r / (float)total;
+        if (D_out) D_out[i] = d;
+    }
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (sh[0] + sh[1] + sh[2] + sh[3]) / (double)total);
+}
+int edm_loss_grad(const float* F, const float* xn, const float* y, const float* coef, int64_t per_sample, int64_t total, float* dF, float* D_out,
+                  double* loss, hipStream_t st) {
+    RALD_CHECK(total > 0 && per_sample > 0 && total % per_sample == 0, "edm_loss_grad: bad sizes");
+    RALD_HIP(hipMemsetAsync(loss, 0, sizeof(double), st));
+    hipLaunchKernelGGL(edm_loss_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, F, xn, y, coef, per_sample, total, dF, D_out, loss);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace rald

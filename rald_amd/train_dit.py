@@ -1,0 +1,185 @@
+"""Training step of the latent denoiser on the HIP kernels (the reference's
+``train_one_epoch`` inner loop, engine_generation.py:90-110, for ``criterion = EDMLoss``):
+
+    sigma = exp(1.2 * N - 1.2); noised = y + sigma * n            (models_radar_generation.py:283-290)
+    D = c_skip * noised + c_out * F(c_in * noised, ln(sigma)/4, cond)   (:422-430)
+    loss = mean((sigma^2 + 1)/sigma^2 * (D - y)^2)                 (:291-295)
+    backward -> clip_grad_norm_(10) -> AdamW -> EMA               (engine_generation.py:96-110)
+
+``DitTrainer`` owns the bf16 compute copies of the fp32 master weights (``FlatAdamW``'s flat storage),
+runs forward + backward of ``LatentArrayTransformer`` with the kernels of ``train_ops`` (24 x
+``block_forward`` / ``block_backward``, plus the timestep-embedding MLP, the AdaLN linears, proj_in / norm /
+proj_out and the loss) and writes every gradient into the parameters' ``.grad`` views of the flat buffer.
+
+Scope: the transformer and the loss, with the radar condition TOKENS as an input (their gradient is
+returned).  The radar encoder's backward (the shipped config trains it jointly, ``unfreeze_radar_enc``) is
+not built, so this is not yet the reference's full training step.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import train_ops as TO
+from ._handles import _stream, op_gemm_nt, op_layernorm
+from ._lib import check, lib
+
+_p = TO._p
+
+
+def sgemm_acc(A, B, out, trans_a=False, trans_b=False, alpha=1.0, M=None, N=None, K=None):
+    """out[m, n] += alpha * sum_k A(m, k) B(n, k) in fp32 (see rald_op_sgemm_acc)."""
+    M = M if M is not None else (A.shape[1] if trans_a else A.shape[0])
+    K = K if K is not None else (A.shape[0] if trans_a else A.shape[1])
+    N = N if N is not None else (B.shape[1] if trans_b else B.shape[0])
+    check(lib().rald_op_sgemm_acc(_p(A), A.stride(0), int(trans_a), _p(B), B.stride(0), int(trans_b), _p(out), out.stride(0), M, N, K, alpha,
+                                  C.c_void_p(_stream())))
+    return out
+
+
+def linear_f32(x, W, b=None):
+    """x [M, K] . W[N, K]^T (+ b) in fp32."""
+    out = b.repeat(x.shape[0], 1).contiguous() if b is not None else torch.zeros(x.shape[0], W.shape[0], device=x.device)
+    return sgemm_acc(x, W, out)
+
+
+def silu(x):
+    y = torch.empty_like(x)
+    check(lib().rald_op_silu_fwd(_p(x), _p(y), x.numel(), C.c_void_p(_stream())))
+    return y
+
+
+def silu_bwd(x_pre, dy):
+    dx = torch.empty_like(x_pre)
+    check(lib().rald_op_silu_bwd(_p(x_pre), _p(dy), _p(dx), x_pre.numel(), C.c_void_p(_stream())))
+    return dx
+
+
+class DitTrainer:
+    """Forward + backward of ``LatentArrayTransformer`` under ``EDMLoss``; gradients go to ``param.grad``."""
+
+    def __init__(self, named_params: Dict[str, torch.nn.Parameter], depth: int, n_heads: int = 8, sigma_data: float = 1.0,
+                 p_mean: float = -1.2, p_std: float = 1.2):
+        self.P = named_params                      # names as in LatentArrayTransformer.state_dict() (no prefix)
+        self.depth, self.H, self.D = depth, n_heads, n_heads * 64
+        self.sigma_data, self.p_mean, self.p_std = sigma_data, p_mean, p_std
+        dev = next(iter(named_params.values())).device
+        if dev.type != "cuda":
+            raise RuntimeError("DitTrainer runs on the HIP device only (no CPU fallback)")
+        self.dev = dev
+        self.W = None
+        self.refresh_weights()
+
+    # -- bf16 compute copies of the master weights (call after every optimizer step) ----------------------
+    def refresh_weights(self) -> None:
+        sd = {k: p.data for k, p in self.P.items()}
+        self.W = [TO.prepare_block_weights(sd, f"transformer_blocks.{i}.", self.dev) for i in range(self.depth)]
+        self.w_mod = torch.cat([sd[f"transformer_blocks.{i}.norm{j}.linear.weight"] for i in range(self.depth) for j in (1, 2, 3)], 0)
+        self.b_mod = torch.cat([sd[f"transformer_blocks.{i}.norm{j}.linear.bias"] for i in range(self.depth) for j in (1, 2, 3)], 0)
+
+    def _grad(self, name: str) -> torch.Tensor:
+        p = self.P[name]
+        if p.grad is None:
+            p.grad = torch.zeros_like(p.data)
+        return p.grad
+
+    def _block_grad_views(self, i: int):
+        """fp32 destinations for block i's gradients, keyed like ``train_ops.prepare_block_weights``: the parameters'
+        own ``.grad`` tensors (views of the optimizer's flat buffer), so the dW GEMMs accumulate in place.  The fused
+        q/k/v gradient needs the three ``.grad`` views to be adjacent (they are in ``FlatAdamW``'s layout)."""
+        pre, D = f"transformer_blocks.{i}.", self.D
+        g = lambda n: self._grad(pre + n)
+        views = {"o": g("attn1.to_out.0.weight"), "bo": g("attn1.to_out.0.bias"), "q2": g("attn2.to_q.weight"), "k2": g("attn2.to_k.weight"),
+                 "v2": g("attn2.to_v.weight"), "o2": g("attn2.to_out.0.weight"), "bo2": g("attn2.to_out.0.bias"),
+                 "w1": g("ff.net.0.proj.weight"), "b1": g("ff.net.0.proj.bias"), "w2": g("ff.net.2.weight"), "b2": g("ff.net.2.bias")}
+        gq, gk, gv = g("attn1.to_q.weight"), g("attn1.to_k.weight"), g("attn1.to_v.weight")
+        step = gq.numel() * 4
+        pending = []
+        if (gq.is_contiguous() and gk.data_ptr() == gq.data_ptr() + step and gv.data_ptr() == gk.data_ptr() + step
+                and gq.untyped_storage().data_ptr() == gv.untyped_storage().data_ptr()):
+            views["qkv"] = torch.as_strided(gq, (3 * D, D), (D, 1))
+        else:
+            pending = [(pre + f"attn1.to_{n}.weight", "qkv", slice(j * D, (j + 1) * D)) for j, n in enumerate("qkv")]
+        return views, pending
+
+    def forward_backward(self, y: torch.Tensor, cond_tokens: torch.Tensor, rnd_normal: torch.Tensor, noise: torch.Tensor):
+        """y [B, N, C] clean latents, cond_tokens [B, T, Cd], rnd_normal [B] and noise [B, N, C] = the two draws of
+        EDMLoss (:285, :288).  Accumulates into every ``param.grad``; returns (loss 0-dim device double, dcond [B, T, Cd])."""
+        P, D, H, L, dev = self.P, self.D, self.H, self.depth, self.dev
+        Bn, NL, Cc = y.shape
+        T = cond_tokens.shape[1]
+        M = Bn * NL
+        f32 = dict(device=dev, dtype=torch.float32)
+        sd2 = self.sigma_data ** 2
+        # per-sample scalars (tiny host math, like the reference's python arithmetic on [B,1,1] tensors)
+        sigma = torch.exp(rnd_normal.double().cpu() * self.p_std + self.p_mean)
+        c_skip, c_out = sd2 / (sigma ** 2 + sd2), sigma * self.sigma_data / torch.sqrt(sigma ** 2 + sd2)
+        c_in, c_noise = 1.0 / torch.sqrt(sd2 + sigma ** 2), torch.log(sigma) / 4
+        weight = (sigma ** 2 + sd2) / (sigma * self.sigma_data) ** 2
+        coef3 = torch.stack([c_skip, c_out, weight], 1).to(**f32).contiguous()
+        y2 = y.reshape(M, Cc).to(**f32).contiguous()
+        xn = (y2.view(Bn, NL * Cc) + noise.reshape(Bn, NL * Cc).to(**f32) * sigma.to(**f32)[:, None]).view(M, Cc).contiguous()
+        xin = (xn.view(Bn, NL * Cc) * c_in.to(**f32)[:, None]).view(M, Cc).contiguous()
+        # ---- timestep embedding (:217-219) and the 72 AdaLN modulations (:127-131) ---------------------------
+        pe = torch.empty(Bn, P["map_layer0.weight"].shape[1], **f32)
+        check(lib().rald_op_posemb(_p(c_noise.to(**f32).contiguous()), _p(pe), Bn, pe.shape[1], C.c_void_p(_stream())))
+        a0 = linear_f32(pe, P["map_layer0.weight"].data, P["map_layer0.bias"].data)
+        e0 = silu(a0)
+        a1 = linear_f32(e0, P["map_layer1.weight"].data, P["map_layer1.bias"].data)
+        temb = silu(a1)
+        mod = linear_f32(temb, self.w_mod, self.b_mod).view(Bn, L * 3, 2 * D)           # [B, 72, 1024]
+        # ---- proj_in, blocks, norm, proj_out ------------------------------------------------------------------
+        x = torch.zeros(M, D, **f32)
+        sgemm_acc(xin, P["proj_in.weight"].data, x)
+        cond16 = TO.cast_bf16(cond_tokens.reshape(Bn * T, -1).to(**f32).contiguous())
+        saved = []
+        for i in range(L):
+            saved.append(TO.block_forward(self.W[i], x, mod[:, 3 * i:3 * i + 3], cond16, Bn, NL, H))
+        x_final = x
+        ng, nb = P["norm.weight"].data, P["norm.bias"].data
+        yn = op_layernorm(x_final, ng, nb, gstride=0, rows_per_group=1 << 30, add_one=0.0).float()      # [M, 512]
+        F = torch.zeros(M, Cc, **f32)
+        sgemm_acc(yn, P["proj_out.weight"].data, F)
+        # ---- loss and its gradient --------------------------------------------------------------------------
+        loss = torch.zeros(1, device=dev, dtype=torch.float64)
+        dF = torch.empty_like(F)
+        check(lib().rald_op_edm_loss_grad(_p(F), _p(xn), _p(y2), _p(coef3), NL * Cc, M * Cc, _p(dF), _p(None), _p(loss), C.c_void_p(_stream())))
+        # ---- backward ---------------------------------------------------------------------------------------
+        sgemm_acc(dF, yn, self._grad("proj_out.weight"), trans_a=True, trans_b=True)             # dW_out = dF^T . yn
+        dyn = torch.zeros(M, D, **f32)
+        sgemm_acc(dF, P["proj_out.weight"].data, dyn, trans_b=True)                              # dyn = dF . W_out
+        dx = torch.zeros(M, D, **f32)
+        TO.ln_mod_bwd(x_final, dyn, ng, 0, 1 << 30, 0.0, dx, self._grad("norm.weight"), self._grad("norm.bias"))
+        dmod = torch.zeros(Bn, L * 3, 2 * D, **f32)
+        dcond = torch.zeros(Bn * T, cond16.shape[1], **f32)
+        for i in reversed(range(L)):
+            grads, pending = self._block_grad_views(i)
+            _, _, dc = TO.block_backward(self.W[i], saved[i], dx, dmod[:, 3 * i:3 * i + 3], grads)
+            saved[i] = None
+            dcond += dc
+            for name, key, rows in pending:                 # q/k/v gradients not adjacent in memory: split the fused one
+                self._grad(name).add_(grads[key][rows])
+        sgemm_acc(dx, xin, self._grad("proj_in.weight"), trans_a=True, trans_b=True)             # dW_in = dx^T . xin
+        # AdaLN linears: mod = temb . w_mod^T + b_mod
+        dmod2 = dmod.view(Bn, L * 3 * 2 * D)
+        gw = torch.zeros_like(self.w_mod)
+        sgemm_acc(dmod2, temb, gw, trans_a=True, trans_b=True)                                   # [73728, 512] = dmod^T . temb
+        gb = torch.zeros(1, dmod2.shape[1], **f32)
+        TO.colsum(dmod2, gb[0])
+        for idx, (i, j) in enumerate((i, j) for i in range(L) for j in (1, 2, 3)):
+            self._grad(f"transformer_blocks.{i}.norm{j}.linear.weight").add_(gw[idx * 2 * D:(idx + 1) * 2 * D])
+            self._grad(f"transformer_blocks.{i}.norm{j}.linear.bias").add_(gb[0, idx * 2 * D:(idx + 1) * 2 * D])
+        dtemb = torch.zeros(Bn, D, **f32)
+        sgemm_acc(dmod2, self.w_mod, dtemb, trans_b=True)                                        # dmod . w_mod
+        da1 = silu_bwd(a1, dtemb)
+        sgemm_acc(da1, e0, self._grad("map_layer1.weight"), trans_a=True, trans_b=True)
+        TO.colsum(da1, self._grad("map_layer1.bias"))
+        de0 = torch.zeros(Bn, D, **f32)
+        sgemm_acc(da1, P["map_layer1.weight"].data, de0, trans_b=True)
+        da0 = silu_bwd(a0, de0)
+        sgemm_acc(da0, pe, self._grad("map_layer0.weight"), trans_a=True, trans_b=True)
+        TO.colsum(da0, self._grad("map_layer0.bias"))
+        return loss[0], dcond.view(Bn, T, -1)

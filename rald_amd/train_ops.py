@@ -127,11 +127,11 @@ def prepare_block_weights(sd: Dict[str, torch.Tensor], prefix: str, device) -> D
 
 
 def block_forward(W, x: torch.Tensor, mod: torch.Tensor, cond: torch.Tensor, Bn: int, NL: int, H: int = 8):
-    """x [Bn*NL, 512] f32 (updated in place), mod [Bn, 3, 1024] f32 = (scale | shift) of norm1..3, cond [Bn*T, Cd] bf16.
-    Returns the saved activations for ``block_backward``."""
+    """x [Bn*NL, 512] f32 (updated in place), mod [Bn, 3, 1024] f32 = (scale | shift) of norm1..3 (may be a strided
+    view of the whole model's table), cond [Bn*T, Cd] bf16.  Returns the saved activations for ``block_backward``."""
     D, M, T = H * HEAD, Bn * NL, cond.shape[0] // Bn
     sv = {"mod": mod, "cond": cond, "Bn": Bn, "NL": NL, "H": H, "T": T}
-    ln = lambda j: op_layernorm(x, mod[:, j, :D], mod[:, j, D:], gstride=3 * 2 * D, rows_per_group=NL, add_one=1.0)
+    ln = lambda j: op_layernorm(x, mod[:, j, :D], mod[:, j, D:], gstride=mod.stride(0), rows_per_group=NL, add_one=1.0)
     sv["x0"] = x.clone()
     sv["h1"] = ln(0)
     qkv = op_gemm_nt(sv["h1"], W["qkv"])                                          # [M, 1536]
@@ -154,22 +154,30 @@ def block_forward(W, x: torch.Tensor, mod: torch.Tensor, cond: torch.Tensor, Bn:
     return sv
 
 
-def block_backward(W, sv, dx: torch.Tensor) -> Tuple[Dict[str, torch.Tensor], torch.Tensor, torch.Tensor]:
+def block_backward(W, sv, dx: torch.Tensor, dmod: torch.Tensor = None, grads: Dict[str, torch.Tensor] = None):
     """dx [M, 512] f32 = gradient w.r.t. the block's output; on return it holds the gradient w.r.t. its input.
-    Returns (weight/bias gradients keyed like ``prepare_block_weights``, dmod [Bn, 3, 1024], dcond [Bn*T, Cd] f32)."""
+    ``dmod`` (same shape AND strides as the ``mod`` given to block_forward, accumulated into) and ``grads`` (fp32
+    destinations keyed like ``prepare_block_weights``, accumulated into - e.g. views of the flat gradient) are
+    allocated when omitted.  Returns (grads, dmod, dcond [Bn*T, Cd] f32)."""
     Bn, NL, H, T, mod, cond = sv["Bn"], sv["NL"], sv["H"], sv["T"], sv["mod"], sv["cond"]
     D, M, dev = H * HEAD, Bn * NL, dx.device
-    G: Dict[str, torch.Tensor] = {}
-    dmod = torch.zeros_like(mod)
-    zeros = lambda n: torch.zeros(n, device=dev, dtype=torch.float32)
-    ms = 3 * 2 * D
+    G: Dict[str, torch.Tensor] = grads if grads is not None else {}
+    if dmod is None:
+        dmod = torch.zeros_like(mod)
+    if dmod.stride() != mod.stride():
+        raise ValueError("block_backward: dmod must have the strides of mod")
+    zeros = lambda *n: torch.zeros(*n, device=dev, dtype=torch.float32)
+    ms = mod.stride(0)
 
-    def lin_bwd(dy_f32_or_bf16, x_in, name, bias=None):
-        """dW[name] = dy^T . x_in ; returns nothing (dX is taken by the caller, which knows the output dtype it wants)."""
-        G[name] = op_gemm_nt(T2(dy_f32_or_bf16), T2(x_in), epilogue=1)
+    def lin_bwd(dy, x_in, name, bias=None):
+        """G[name] += dy^T . x_in (and G[bias] += column sums of dy)"""
+        if name not in G:
+            G[name] = zeros(dy.shape[1], x_in.shape[1])
+        op_gemm_nt(T2(dy), T2(x_in), epilogue=2, C_inout=G[name])
         if bias is not None:
-            G[bias] = zeros(dy_f32_or_bf16.shape[1])
-            colsum(dy_f32_or_bf16, G[bias])
+            if bias not in G:
+                G[bias] = zeros(dy.shape[1])
+            colsum(dy, G[bias])
 
     def ada_bwd(j, x_saved, dh):
         ln_mod_bwd(x_saved, dh, mod[:, j, :D], ms, NL, 1.0, dx, dmod[:, j, :D], dmod[:, j, D:])

@@ -121,3 +121,53 @@ def test_block_forward_backward_vs_oracle_autograd():
         print(f"  grad {name:16s} rel_l2 {e:.2e}")
         assert e < 3e-2, name
     print("worst gradient rel_l2", worst)
+
+
+def test_dit_train_step_gradients_vs_oracle_autograd_and_loss_decreases():
+    """Whole LatentArrayTransformer (depth 2) under EDMLoss: loss value and EVERY parameter gradient against
+    autograd of the CPU oracle with the same two random draws; then five optimizer steps (clip 10 -> AdamW -> EMA
+    on the flat storage) on one batch must lower the loss."""
+    from oracle import rald_oracle as O
+    from rald_amd import models_radar_generation as G, train_dit as TD
+    from rald_amd.train_utils import FlatAdamW
+    depth, Bn, NL, Cc, T = 2, 2, 512, 32, 64
+    sd = weights.make_state_dict(weights.dit_spec(depth=depth, with_radar=False, prefix="model."), 0)
+    y = synth.normal([Bn, NL, Cc], 530)
+    cond = synth.cond_tokens(Bn, T, 512, seed=531)
+    rnd, noise = synth.normal([Bn, 1, 1], 532), synth.normal([Bn, NL, Cc], 533)
+    leaf = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    cond_leaf = cond.clone().requires_grad_()
+    loss_ref = O.edm_loss(leaf, y, cond_leaf, rnd, noise, depth)
+    loss_ref.backward()
+
+    m = G.LatentArrayTransformer(in_channels=Cc, t_channels=256, n_heads=8, d_head=64, depth=depth)
+    m.load_state_dict({k[len("model."):]: v for k, v in sd.items()}, strict=True)
+    m = m.cuda()
+    named = dict(m.named_parameters())
+    opt = FlatAdamW(list(named.values()), lr=2e-4, ema=True)
+    tr = TD.DitTrainer(named, depth)
+    loss, dcond = tr.forward_backward(y.cuda(), cond.cuda(), rnd.flatten(), noise.cuda())
+    torch.cuda.synchronize()
+    loss_ref = loss_ref.detach()
+    print("EDM loss hip / oracle:", float(loss), float(loss_ref))
+    assert abs(float(loss) - float(loss_ref)) < 5e-3 * float(loss_ref)
+    worst = ("", 0.0)
+    for k, p in named.items():
+        e = rel_l2(p.grad.cpu(), leaf["model." + k].grad)
+        if e > worst[1]:
+            worst = (k, e)
+        assert e < 4e-2, (k, e)
+    print("worst parameter-gradient rel_l2:", worst)
+    e = rel_l2(dcond.cpu(), cond_leaf.grad)
+    print("dcond rel_l2", e)
+    assert e < 4e-2
+    losses = [float(loss)]
+    for _ in range(5):
+        opt.clip_grad_norm_(10.0)
+        opt.step(ema_rate=0.999)
+        tr.refresh_weights()
+        opt.zero_grad()
+        l, _ = tr.forward_backward(y.cuda(), cond.cuda(), rnd.flatten(), noise.cuda())
+        losses.append(float(l))
+    print("losses over 5 steps on one batch:", [round(v, 4) for v in losses])
+    assert losses[-1] < 0.9 * losses[0]
