@@ -13,22 +13,59 @@
 namespace rald {
 
 // ---- batched 2-D transpose with cast to bf16: in [rows][cols] (f32 or bf16) -> out [cols][rows] bf16 -------
+// 64x64 tiles through LDS; 16-byte global accesses on both sides when the shapes allow (every use in the training
+// step does: rows, cols, leading dimensions multiples of 8), element-wise otherwise.
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_rows_kernel(TransposeArgs a) {
-    __shared__ float tile[64][65];
+    __shared__ bf16 tile[64][72];                             // [row][col], 144-byte rows: 16-byte aligned, conflict-light
     const int b1 = blockIdx.z / a.batch2, b2 = blockIdx.z - b1 * a.batch2;
     const T* in = reinterpret_cast<const T*>(a.in) + (int64_t)b1 * a.stride_in + (int64_t)b2 * a.stride_in2;
     bf16* out = a.out + (int64_t)b1 * a.stride_out + (int64_t)b2 * a.stride_out2;
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const bool vec = (a.rows % 8 == 0) && (a.cols % 8 == 0) && (a.ld_in % 8 == 0) && (a.ld_out % 8 == 0) && (a.stride_in % 8 == 0) &&
+                     (a.stride_in2 % 8 == 0) && (a.stride_out % 8 == 0) && (a.stride_out2 % 8 == 0) &&
+                     ((uintptr_t)a.in % 16 == 0) && ((uintptr_t)a.out % 16 == 0);
+    if (vec) {
+        // load: thread -> (row = tid / 8 (+32), 8 consecutive columns)
+        for (int p = 0; p < 2; ++p) {
+            const int r = (threadIdx.x >> 3) + 32 * p, c = (threadIdx.x & 7) * 8;
+            bf16x8 v;
+            if (r0 + r < a.rows && c0 + c < a.cols) {
+                const T* src = in + (int64_t)(r0 + r) * a.ld_in + c0 + c;
+                if constexpr (sizeof(T) == 4) {
+                    const float4 x = *reinterpret_cast<const float4*>(src), y = *reinterpret_cast<const float4*>(src + 4);
+                    v = bf16x8{(bf16)x.x, (bf16)x.y, (bf16)x.z, (bf16)x.w, (bf16)y.x, (bf16)y.y, (bf16)y.z, (bf16)y.w};
+                } else {
+                    v = *reinterpret_cast<const bf16x8*>(src);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = (bf16)0.f;
+            }
+            *reinterpret_cast<bf16x8*>(&tile[r][c]) = v;
+        }
+        __syncthreads();
+        // store: thread -> (output row = input column c = tid / 8 (+32), 8 consecutive input rows)
+        for (int p = 0; p < 2; ++p) {
+            const int c = (threadIdx.x >> 3) + 32 * p, r = (threadIdx.x & 7) * 8;
+            if (c0 + c < a.cols && r0 + r < a.rows) {
+                bf16x8 v;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = tile[r + i][c];
+                *reinterpret_cast<bf16x8*>(out + (int64_t)(c0 + c) * a.ld_out + r0 + r) = v;
+            }
+        }
+        return;
+    }
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int i = ty; i < 64; i += 4) {
         const int r = r0 + i, c = c0 + tx;
-        tile[i][tx] = (r < a.rows && c < a.cols) ? (float)in[(int64_t)r * a.ld_in + c] : 0.f;
+        tile[i][tx] = (r < a.rows && c < a.cols) ? (bf16)(float)in[(int64_t)r * a.ld_in + c] : (bf16)0.f;
     }
     __syncthreads();
     for (int i = ty; i < 64; i += 4) {
         const int c = c0 + i, r = r0 + tx;
-        if (c < a.cols && r < a.rows) out[(int64_t)c * a.ld_out + r] = (bf16)tile[tx][i];
+        if (c < a.cols && r < a.rows) out[(int64_t)c * a.ld_out + r] = tile[tx][i];
     }
 }
 
@@ -175,7 +212,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, in
 }
 int colsum(const void* X, int is_bf16, int64_t ld, int64_t M, int N, float* out, hipStream_t st) {
     RALD_CHECK(M > 0 && N > 0 && X && out, "colsum: bad arguments");
-    const int rpb = 128;
+    const int rpb = M >= 4096 ? 32 : 16;           // enough row blocks to cover the chip (N is 512..4096 here)
     dim3 grid(cdiv(N, 256), (unsigned)((M + rpb - 1) / rpb));
     if (is_bf16) hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)X, ld, M, N, rpb, out);
     else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)X, ld, M, N, rpb, out);

@@ -74,11 +74,52 @@ class DitTrainer:
         self.refresh_weights()
 
     # -- bf16 compute copies of the master weights (call after every optimizer step) ----------------------
+    _MATS = (("qkv", "attn1.to_q.weight", 3), ("o", "attn1.to_out.0.weight", 1), ("q2", "attn2.to_q.weight", 1), ("k2", "attn2.to_k.weight", 1),
+             ("v2", "attn2.to_v.weight", 1), ("o2", "attn2.to_out.0.weight", 1), ("w1", "ff.net.0.proj.weight", 1), ("w2", "ff.net.2.weight", 1))
+    _VECS = (("bo", "attn1.to_out.0.bias"), ("bo2", "attn2.to_out.0.bias"), ("b1", "ff.net.0.proj.bias"), ("b2", "ff.net.2.bias"))
+
+    def _regular_layout(self):
+        """(element offsets of block 0's matrices relative to block 0's first one, block stride) when every block's
+        parameters sit at the same relative offsets of ONE fp32 buffer (``FlatAdamW``'s layout), else None."""
+        if self.depth < 1:
+            return None
+        key = lambda i, n: self.P[f"transformer_blocks.{i}.{n}"]
+        base0 = key(0, self._MATS[0][1])
+        store = base0.untyped_storage().data_ptr()
+        stride = (key(1, self._MATS[0][1]).data_ptr() - base0.data_ptr()) // 4 if self.depth > 1 else 0
+        for i in range(self.depth):
+            for _, n, mult in self._MATS:
+                p = key(i, n)
+                if p.untyped_storage().data_ptr() != store or not p.is_contiguous():
+                    return None
+                if p.data_ptr() - key(0, n).data_ptr() != i * stride * 4:
+                    return None
+            q, k, v = key(i, "attn1.to_q.weight"), key(i, "attn1.to_k.weight"), key(i, "attn1.to_v.weight")
+            if k.data_ptr() != q.data_ptr() + q.numel() * 4 or v.data_ptr() != k.data_ptr() + k.numel() * 4:
+                return None
+        return stride
+
     def refresh_weights(self) -> None:
         sd = {k: p.data for k, p in self.P.items()}
-        self.W = [TO.prepare_block_weights(sd, f"transformer_blocks.{i}.", self.dev) for i in range(self.depth)]
-        self.w_mod = torch.cat([sd[f"transformer_blocks.{i}.norm{j}.linear.weight"] for i in range(self.depth) for j in (1, 2, 3)], 0)
-        self.b_mod = torch.cat([sd[f"transformer_blocks.{i}.norm{j}.linear.bias"] for i in range(self.depth) for j in (1, 2, 3)], 0)
+        L = self.depth
+        stride = self._regular_layout()
+        if stride is None:                                  # arbitrary parameter tensors: per-tensor casts and transposes
+            self.W = [TO.prepare_block_weights(sd, f"transformer_blocks.{i}.", self.dev) for i in range(L)]
+        else:
+            # one strided launch per matrix kind for all blocks: fp32 master -> bf16 [L, rows, cols] and its transpose
+            self.W = [dict() for _ in range(L)]
+            for key, n, mult in self._MATS:
+                p0 = sd[f"transformer_blocks.0.{n}"]
+                rows, cols = p0.shape[0] * mult, p0.shape[1]
+                wt = TO.transpose(p0, rows, cols, cols, batch=L, stride_in=stride).view(L, cols, rows)          # W^T (bf16)
+                w = TO.transpose(wt, cols, rows, rows, batch=L, stride_in=cols * rows).view(L, rows, cols)      # W   (bf16)
+                for i in range(L):
+                    self.W[i][key], self.W[i][key + "T"] = w[i], wt[i]
+            for i in range(L):
+                for key, n in self._VECS:
+                    self.W[i][key] = sd[f"transformer_blocks.{i}.{n}"]
+        self.w_mod = torch.cat([sd[f"transformer_blocks.{i}.norm{j}.linear.weight"] for i in range(L) for j in (1, 2, 3)], 0)
+        self.b_mod = torch.cat([sd[f"transformer_blocks.{i}.norm{j}.linear.bias"] for i in range(L) for j in (1, 2, 3)], 0)
 
     def _grad(self, name: str) -> torch.Tensor:
         p = self.P[name]
@@ -105,27 +146,37 @@ class DitTrainer:
             pending = [(pre + f"attn1.to_{n}.weight", "qkv", slice(j * D, (j + 1) * D)) for j, n in enumerate("qkv")]
         return views, pending
 
+    def edm_scalars(self, rnd_normal: torch.Tensor) -> torch.Tensor:
+        """[B, 6] device table {sigma, c_in, c_noise, c_skip, c_out, weight} from the log-normal draw (:285-286, :422-425);
+        tiny host math, like the reference's python arithmetic on [B,1,1] tensors."""
+        sd2 = self.sigma_data ** 2
+        sigma = torch.exp(rnd_normal.double().cpu().flatten() * self.p_std + self.p_mean)
+        c_skip, c_out = sd2 / (sigma ** 2 + sd2), sigma * self.sigma_data / torch.sqrt(sigma ** 2 + sd2)
+        c_in, c_noise = 1.0 / torch.sqrt(sd2 + sigma ** 2), torch.log(sigma) / 4
+        weight = (sigma ** 2 + sd2) / (sigma * self.sigma_data) ** 2
+        return torch.stack([sigma, c_in, c_noise, c_skip, c_out, weight], 1).to(device=self.dev, dtype=torch.float32).contiguous()
+
     def forward_backward(self, y: torch.Tensor, cond_tokens: torch.Tensor, rnd_normal: torch.Tensor, noise: torch.Tensor):
         """y [B, N, C] clean latents, cond_tokens [B, T, Cd], rnd_normal [B] and noise [B, N, C] = the two draws of
         EDMLoss (:285, :288).  Accumulates into every ``param.grad``; returns (loss 0-dim device double, dcond [B, T, Cd])."""
+        return self.forward_backward_device(y, cond_tokens, self.edm_scalars(rnd_normal), noise)
+
+    def forward_backward_device(self, y: torch.Tensor, cond_tokens: torch.Tensor, scal: torch.Tensor, noise: torch.Tensor):
+        """Same with the per-sample scalars already on the device (``edm_scalars``): nothing here touches the host, so
+        the whole call can be captured in a hipGraph (``GraphedTrainStep``)."""
         P, D, H, L, dev = self.P, self.D, self.H, self.depth, self.dev
         Bn, NL, Cc = y.shape
         T = cond_tokens.shape[1]
         M = Bn * NL
         f32 = dict(device=dev, dtype=torch.float32)
-        sd2 = self.sigma_data ** 2
-        # per-sample scalars (tiny host math, like the reference's python arithmetic on [B,1,1] tensors)
-        sigma = torch.exp(rnd_normal.double().cpu() * self.p_std + self.p_mean)
-        c_skip, c_out = sd2 / (sigma ** 2 + sd2), sigma * self.sigma_data / torch.sqrt(sigma ** 2 + sd2)
-        c_in, c_noise = 1.0 / torch.sqrt(sd2 + sigma ** 2), torch.log(sigma) / 4
-        weight = (sigma ** 2 + sd2) / (sigma * self.sigma_data) ** 2
-        coef3 = torch.stack([c_skip, c_out, weight], 1).to(**f32).contiguous()
+        sigma, c_in, c_noise = scal[:, 0], scal[:, 1], scal[:, 2].contiguous()
+        coef3 = scal[:, 3:6].contiguous()
         y2 = y.reshape(M, Cc).to(**f32).contiguous()
-        xn = (y2.view(Bn, NL * Cc) + noise.reshape(Bn, NL * Cc).to(**f32) * sigma.to(**f32)[:, None]).view(M, Cc).contiguous()
-        xin = (xn.view(Bn, NL * Cc) * c_in.to(**f32)[:, None]).view(M, Cc).contiguous()
+        xn = (y2.view(Bn, NL * Cc) + noise.reshape(Bn, NL * Cc).to(**f32) * sigma[:, None]).view(M, Cc).contiguous()
+        xin = (xn.view(Bn, NL * Cc) * c_in[:, None]).view(M, Cc).contiguous()
         # ---- timestep embedding (:217-219) and the 72 AdaLN modulations (:127-131) ---------------------------
         pe = torch.empty(Bn, P["map_layer0.weight"].shape[1], **f32)
-        check(lib().rald_op_posemb(_p(c_noise.to(**f32).contiguous()), _p(pe), Bn, pe.shape[1], C.c_void_p(_stream())))
+        check(lib().rald_op_posemb(_p(c_noise), _p(pe), Bn, pe.shape[1], C.c_void_p(_stream())))
         a0 = linear_f32(pe, P["map_layer0.weight"].data, P["map_layer0.bias"].data)
         e0 = silu(a0)
         a1 = linear_f32(e0, P["map_layer1.weight"].data, P["map_layer1.bias"].data)
@@ -183,3 +234,54 @@ class DitTrainer:
         sgemm_acc(da0, pe, self._grad("map_layer0.weight"), trans_a=True, trans_b=True)
         TO.colsum(da0, self._grad("map_layer0.bias"))
         return loss[0], dcond.view(Bn, T, -1)
+
+
+class GraphedTrainStep:
+    """One training iteration with its ~2 200 kernel launches captured in two hipGraphs (torch.cuda.CUDAGraph on the
+    current stream; the library only enqueues on the stream it is given):
+      graph A = zero_grad + forward + backward (static input buffers),
+      eager   = clip_grad_norm_ + fused AdamW/EMA (3 launches; the bias corrections depend on the step count),
+      graph B = refresh of the bf16 weight copies and their transposes.
+    Shapes are fixed at construction (the reference's training batches are fixed-size, drop_last=True)."""
+
+    def __init__(self, trainer: DitTrainer, opt, Bn: int, NL: int, Cc: int, T: int, Cd: int):
+        self.tr, self.opt = trainer, opt
+        dev = trainer.dev
+        z = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)
+        self.y, self.cond, self.noise, self.scal = z(Bn, NL, Cc), z(Bn, T, Cd), z(Bn, NL, Cc), z(Bn, 6)
+        self.scal[:, 0] = 1.0
+        self.scal[:, 5] = 1.0
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                          # warm-up outside capture (lazy allocations, function attributes)
+            opt.zero_grad()
+            trainer.forward_backward_device(self.y, self.cond, self.scal, self.noise)
+            trainer.refresh_weights()
+            opt.zero_grad()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.g_refresh = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_refresh):
+            trainer.refresh_weights()                          # trainer.W now lives in the graph's pool, rewritten by every replay
+        self.g_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fb):
+            opt.zero_grad()
+            self.loss, self.dcond = trainer.forward_backward_device(self.y, self.cond, self.scal, self.noise)
+        self.g_refresh.replay()
+
+    def __call__(self, y, cond_tokens, rnd_normal, noise, max_norm: float = 10.0, ema_rate: Optional[float] = 0.999, pre_scale: float = 1.0,
+                 reducer=None):
+        """Returns (loss, total gradient norm) as 0-dim device tensors.  ``reducer`` (``GradReducer``) exchanges the flat
+        gradient between ranks after the backward graph; pass its ``pre_scale`` = 1/world."""
+        self.y.copy_(y, non_blocking=True)
+        self.cond.copy_(cond_tokens, non_blocking=True)
+        self.noise.copy_(noise, non_blocking=True)
+        self.scal.copy_(self.tr.edm_scalars(rnd_normal), non_blocking=True)
+        self.g_fb.replay()
+        if reducer is not None:
+            reducer.start()
+            pre_scale = reducer.finish()
+        norm = self.opt.clip_grad_norm_(max_norm, pre_scale=pre_scale)
+        self.opt.step(ema_rate=ema_rate)
+        self.g_refresh.replay()
+        return self.loss, norm

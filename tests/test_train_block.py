@@ -171,3 +171,40 @@ def test_dit_train_step_gradients_vs_oracle_autograd_and_loss_decreases():
         losses.append(float(l))
     print("losses over 5 steps on one batch:", [round(v, 4) for v in losses])
     assert losses[-1] < 0.9 * losses[0]
+
+
+def test_graphed_train_step_equals_eager():
+    """The hipGraph-captured iteration (GraphedTrainStep) must reproduce the eager one: same loss and parameters
+    after two steps, up to the run-to-run noise of the fp32 atomics in the reduction kernels (Adam's first steps
+    are ~lr*sign(g), so a reordered sum can flip the update of a near-zero gradient): losses 5e-4, parameters 1e-3."""
+    from rald_amd import models_radar_generation as G, train_dit as TD
+    from rald_amd.train_utils import FlatAdamW
+    depth, Bn, NL, Cc, T = 2, 2, 512, 32, 64
+    sd = weights.make_state_dict(weights.dit_spec(depth=depth, with_radar=False, prefix=""), 0)
+    y, cond = synth.normal([Bn, NL, Cc], 540).cuda(), synth.cond_tokens(Bn, T, 512, seed=541).cuda()
+    draws = [(synth.normal([Bn], 542 + i), synth.normal([Bn, NL, Cc], 550 + i).cuda()) for i in range(2)]
+
+    def fresh():
+        m = G.LatentArrayTransformer(in_channels=Cc, t_channels=256, n_heads=8, d_head=64, depth=depth)
+        m.load_state_dict(sd, strict=True)
+        named = dict(m.cuda().named_parameters())
+        opt = FlatAdamW(list(named.values()), lr=2e-4, ema=True)
+        return named, opt, TD.DitTrainer(named, depth)
+
+    named, opt, tr = fresh()
+    eager = []
+    for rnd, noise in draws:
+        opt.zero_grad()
+        loss, _ = tr.forward_backward(y, cond, rnd, noise)
+        opt.clip_grad_norm_(10.0)
+        opt.step(ema_rate=0.999)
+        tr.refresh_weights()
+        eager.append(float(loss))
+    p_eager = opt.flat_p.clone()
+    named, opt, tr = fresh()
+    step = TD.GraphedTrainStep(tr, opt, Bn, NL, Cc, T, 512)
+    graphed = [float(step(y, cond, rnd, noise)[0]) for rnd, noise in draws]
+    print("eager losses", eager, "graphed", graphed)
+    assert all(abs(a - b) < 5e-4 * abs(a) for a, b in zip(eager, graphed))
+    print("parameters after two steps, graphed vs eager rel_l2:", rel_l2(opt.flat_p, p_eager))
+    assert rel_l2(opt.flat_p, p_eager) < 1e-3

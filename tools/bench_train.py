@@ -1,6 +1,6 @@
 """Scratch: time of one training step of the 24-block denoiser (forward + backward + clip/AdamW/EMA), B per GPU."""
 import sys, time, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rald_amd import models_radar_generation as G, synth, train_dit as TD, weights
 from rald_amd.train_utils import FlatAdamW
 
@@ -31,4 +31,12 @@ for B in Bs:
     t1 = time.perf_counter()
     tr.forward_backward(y, cond, rnd, noise); torch.cuda.synchronize()
     fb = time.perf_counter() - t1
+    gstep = TD.GraphedTrainStep(tr, opt, B, 512, 32, 64, 512)
+    for _ in range(2): gstep(y, cond, rnd, noise)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for _ in range(n): lg, _ = gstep(y, cond, rnd, noise)
+    torch.cuda.synchronize()
+    dg = (time.perf_counter() - t2) / n
+    print(f"B={B:3d}: graphed {dg*1e3:8.1f} ms/step ({B/dg:7.1f} samples/s, {3*132.18*B/dg/1e3:6.1f} TFLOP/s at 3x fwd FLOPs); loss {float(lg):.4f}", flush=True)
     print(f"B={B:3d}: {dt*1e3:8.1f} ms/step ({B/dt:7.1f} samples/s, {3*132.18*B/dt/1e3:6.1f} TFLOP/s at 3x fwd FLOPs); fwd+bwd alone {fb*1e3:7.1f} ms; loss {float(l):.4f}", flush=True)
