@@ -33,4 +33,50 @@ def run(dit_handle) -> dict:
         out.update(bench_ae.run())
     except ImportError:
         pass
+    for name, fn in (("fp8", _fp8_mode), ("train", _train_step)):
+        try:
+            out.update(fn())
+        except Exception as e:          # secondary numbers never invalidate the headline line
+            out[f"{name}_error"] = repr(e)
     return out
+
+
+def _denoiser(depth=24):
+    from . import models_radar_generation as G, weights
+    m = G.LatentArrayTransformer(in_channels=32, t_channels=256, n_heads=8, d_head=64, depth=depth)
+    m.load_state_dict(weights.make_state_dict(weights.dit_spec(depth=depth, with_radar=False, prefix=""), 0))
+    return m.cuda()
+
+
+def _fp8_mode(B=64) -> dict:
+    """BASELINE config #5: one NFE with MXFP8 attention projections (qkv_dtype='fp8'), same batch as the headline."""
+    m = _denoiser()
+    m.qkv_dtype = "fp8"
+    h = m._handle(512, 64)
+    h.set_sigmas([1.0])
+    x = synth.latents(range(B)).cuda()
+    cache = h.encode_cond_tokens(synth.cond_tokens(B).cuda())
+    dt = _time(lambda: h.denoise(x, cache, 0), reps=10, warm=3)
+    return {"fp8_qkv_nfe_ms_B64": dt * 1e3, "fp8_qkv_sample_nfe_per_s": B / dt}
+
+
+def _train_step(B=8) -> dict:
+    """one training iteration of the 24-block denoiser under EDMLoss (forward + backward + clip +
+    fused AdamW/EMA + weight refresh), condition tokens given, B = the reference's per-GPU training batch."""
+    from . import train_dit as TD
+    from .train_utils import FlatAdamW
+    m = _denoiser()
+    named = dict(m.named_parameters())
+    opt = FlatAdamW(list(named.values()), lr=1e-4, ema=True)
+    tr = TD.DitTrainer(named, 24)
+    y, cond = synth.normal([B, 512, 32], 1).cuda(), synth.cond_tokens(B).cuda()
+    rnd, noise = synth.normal([B], 2), synth.normal([B, 512, 32], 3).cuda()
+
+    def step():
+        opt.zero_grad()
+        tr.forward_backward(y, cond, rnd, noise)
+        opt.clip_grad_norm_(10.0)
+        opt.step(ema_rate=0.999)
+        tr.refresh_weights()
+    dt = _time(step, reps=4, warm=2)
+    return {"train_step_ms_B8": dt * 1e3, "train_samples_per_s_B8": B / dt}

@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rald_amd import _handles as H
 def run(M,N,K,epi,impl,abl,reps=20):
     os.environ["RALD_GEMM_IMPL"]=str(impl); os.environ["RALD_GEMM_ABLATE"]=str(abl)

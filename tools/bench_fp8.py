@@ -1,6 +1,6 @@
 """Scratch microbench: MXFP8 GEMM vs bf16 GEMM on the denoiser's QKV / proj shapes."""
 import sys, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rald_amd import _handles as H
 
 def timeit(f, reps=20):

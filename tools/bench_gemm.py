@@ -1,7 +1,7 @@
 """Scratch microbench: the denoiser's GEMM shapes through rald_op_gemm_nt, interleaved A/B of
 kernel variants (env RALD_GEMM_IMPL is read per launch by the library)."""
 import os, sys, time, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rald_amd import _handles as H
 
 def run(M, N, K, epi, impl, reps=20):

@@ -1,6 +1,6 @@
 """Scratch: fused residual-GEMM + LayerNorm (gemm_resid_ln) vs EPI_RESID GEMM + separate LayerNorm."""
 import sys, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rald_amd import _handles as H
 
 def timeit(f, reps=20):

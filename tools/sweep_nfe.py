@@ -1,6 +1,6 @@
 """Scratch perf probe: ms per NFE of the 24-block denoiser vs batch (cond tokens given)."""
 import sys, time, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rald_amd import models_radar_generation as G, weights, synth
 
 depth = 24
