@@ -107,3 +107,38 @@ def gather_shards(local: torch.Tensor, counts: Sequence[int]) -> torch.Tensor | 
     if rank != 0:
         return None
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+
+
+def all_gather_shards(local: torch.Tensor, counts: Sequence[int], dim: int = 0) -> torch.Tensor:
+    """Every rank gets the concatenation (rank order) of the per-rank shards along `dim`; shard lengths may differ
+    (padded to the longest for the collective) and may be zero."""
+    if not is_dist():
+        return local
+    world = dist.get_world_size()
+    loc = local.movedim(dim, 0).contiguous()
+    mx = max(max(counts), 1)
+    pad = torch.zeros((mx,) + tuple(loc.shape[1:]), dtype=loc.dtype, device=loc.device)
+    pad[: loc.shape[0]] = loc
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0).movedim(0, dim)
+
+
+def decode_queries_sharded(vae, z: torch.Tensor, queries: torch.Tensor) -> torch.Tensor:
+    """Second-level split for evaluation at batch 1: the Q ~ 1.2 M decode queries of ONE sample are
+    independent given the latents, so each rank decodes a contiguous slice of them against its own copy of the latent
+    context (every rank holds z - sampling is replicated or z is broadcast by the caller; recomputing the 24-layer
+    latent stack costs 1.4 ms, less than shipping queries around) and the logits are all-gathered: one collective of
+    Q floats per frame.  z [B, M, C], queries [B, Q, 3] (identical on all ranks) -> logits [B, Q, 1] on every rank."""
+    world = world_size()
+    if world == 1:
+        return vae.decode(z, queries)
+    rank = dist.get_rank()
+    Q = queries.shape[1]
+    spans = [shard_bounds(Q, r, world) for r in range(world)]
+    lo, hi = spans[rank]
+    if hi > lo:
+        local = vae.decode(z, queries[:, lo:hi].contiguous())
+    else:
+        local = torch.zeros(queries.shape[0], 0, 1, dtype=torch.float32, device=queries.device)
+    return all_gather_shards(local, [b - a for a, b in spans], dim=1)

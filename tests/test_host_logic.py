@@ -72,6 +72,51 @@ def test_world_size_2_gloo_collectives():
     assert res[0][5] == [0.0, 1.0, 2.0, 3.0, 4.0] and res[1][5] is None
 
 
+class _FakeVae:
+    """decode = a deterministic function of the queries alone (what the real decoder is, given z)."""
+    calls = 0
+
+    def decode(self, z, queries):
+        _FakeVae.calls += 1
+        return (queries * torch.tensor([1.0, -2.0, 0.5])).sum(-1, keepdim=True) + z.sum()
+
+
+def _qsplit_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from rald_amd import distributed as D, synth
+    D.init_distributed(backend="gloo")
+    z = torch.ones(1, 4, 2)
+    out = {}
+    for Q in (1001, 2, 1, 0):                                   # ragged, Q == world, Q < world, empty
+        queries = synth.queries(1, Q, seed=90) if Q else torch.zeros(1, 0, 3)
+        out[Q] = D.decode_queries_sharded(_FakeVae(), z, queries)
+    q.put((rank, {k: v.numpy() for k, v in out.items()}, _FakeVae.calls))
+    torch.distributed.destroy_process_group()
+
+
+def test_query_sharded_decode_gloo_world2():
+    """SURVEY.md §8e second-level split: each rank decodes a slice of one sample's queries, all ranks end with all logits."""
+    from rald_amd import synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_qsplit_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    vae, z = _FakeVae(), torch.ones(1, 4, 2)
+    for rank, outs, calls in res:
+        for Q, got in outs.items():
+            queries = synth.queries(1, Q, seed=90) if Q else torch.zeros(1, 0, 3)
+            want = vae.decode(z, queries).numpy()
+            assert got.shape == (1, Q, 1) and (got == want).all()
+    assert res[0][2] == 3 and res[1][2] == 2                    # rank 1 has no queries at Q = 1; nobody decodes at Q = 0
+
+
 def test_c_abi_library_loads_and_exports_every_declared_symbol():
     """Every function include/rald_hip.h declares must be exported by librald_hip.so and bound in
     rald_amd._lib.SIGNATURES (no compute calls here: there is no GPU)."""
