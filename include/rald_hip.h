@@ -268,6 +268,35 @@ int rald_op_posemb(const float* t, float* out, int32_t n, int32_t channels, void
  * D = c_skip*x_noised + c_out*F; *loss = mean(weight*(D - y)^2) (device double); dF = dloss/dF; D_out optional */
 int rald_op_edm_loss_grad(const float* F, const float* x_noised, const float* y, const float* coef3, int64_t per_sample, int64_t total, float* dF,
                           float* D_out, double* loss, void* stream);
+/* Radar-spectrum encoder at op level (model/models_radar_encoder.py:29-241), channels-last activations
+ * [b][d][h][w][c]: the forward kernels of rald_radar_encode plus the backward building blocks (the shipped
+ * configuration trains the encoder jointly with the denoiser). */
+/* Conv3d k3 as implicit GEMM: in bf16 [B][ID][IH][IW][Cin], w packed bf16 [Cout][27][Cin] (rald_op_conv_pack_weights),
+ * out f32 [B][ID/s][IH/s][IW/s][Cout] = conv + bias (+ resid).  Cin % 64 == 0, Cout % 4 == 0, stride 1|2. */
+int rald_op_conv3d(const void* in_bf16, const void* w_packed_bf16, const float* bias, const float* resid, float* out, int32_t B, int32_t ID,
+                   int32_t IH, int32_t IW, int32_t Cin, int32_t Cout, int32_t stride, int32_t pad, void* stream);
+/* W [Cout][Cin][27] f32 (the parameter) -> packed bf16: dgrad = 0: [Cout][27][pad_to >= Cin]; dgrad = 1: the flipped,
+ * transposed weights [Cin][27][pad_to >= Cout] that make rald_op_conv3d map dY to dX */
+int rald_op_conv_pack_weights(const float* W, void* out_bf16, int32_t Cout, int32_t Cin, int32_t pad_to, int32_t dgrad, void* stream);
+/* Normalize :9-12 (GroupNorm 32 groups, eps 1e-6) [+ swish :5-7]: y bf16; stats [B][32][2] doubles = {sum, sumsq} kept for backward */
+int rald_op_groupnorm(const float* x, const float* gamma, const float* beta, void* y_bf16, double* stats, int32_t B, int32_t S, int32_t C,
+                      int32_t swish, void* stream);
+/* its backward: da = gradient w.r.t. the (activated) output; dx written or accumulated; dgamma/dbeta accumulated; gsum_scratch [B][32][2] doubles */
+int rald_op_groupnorm_bwd(const float* x, const double* stats, const float* gamma, const float* beta, const float* da, float* dx, float* dgamma,
+                          float* dbeta, double* gsum_scratch, int32_t B, int32_t S, int32_t C, int32_t swish, int32_t accumulate, void* stream);
+/* conv_in (Cin = 1 read in place from channel 0 of the cube) and its weight gradient dW [Cout][27] (accumulated) */
+int rald_op_conv_in(const float* cube, int32_t cube_ch, int32_t Cin, const float* W, const float* bias, float* out, int32_t B, int32_t D, int32_t H,
+                    int32_t Wd, int32_t Cout, void* stream);
+int rald_op_conv_in_wgrad(const float* cube, int32_t cube_ch, const float* dy, int32_t B, int32_t D, int32_t H, int32_t Wd, int32_t Cout, float* dW,
+                          void* stream);
+/* x [M][C] f32 -> bf16 [M][Cpad] zero-filled;  dY [B][OD][OH][OW][C] f32 -> bf16 on the even positions of a 2x grid (Downsample dgrad) */
+int rald_op_pad_channels(const float* x, void* out_bf16, int64_t M, int32_t C, int32_t Cpad, void* stream);
+int rald_op_zero_insert2(const float* dy, void* out_bf16, int32_t B, int32_t OD, int32_t OH, int32_t OW, int32_t C, void* stream);
+/* transposed im2col of output voxels [m0, m0+nchunk): out bf16 [C*27][nchunk], row ci*27 + tap (the weight tensor's own order) */
+int rald_op_im2col_t(const void* x_bf16, void* out_bf16, int32_t B, int32_t ID, int32_t IH, int32_t IW, int32_t C, int32_t stride, int32_t pad,
+                     int64_t m0, int32_t nchunk, void* stream);
+int rald_op_rowdot(const void* a_bf16, const void* b_bf16, int64_t M, int32_t C, float* out, void* stream);
+int rald_op_softmax_rows(const float* S, int64_t ld_s, void* P_bf16, int64_t ld_p, int32_t rows, int32_t n, void* stream);
 /* MXFP8 (OCP microscaling: e4m3 elements + one e8m0 scale per 32 consecutive K elements of a row), the
  * "fp8 MFMA QKV/proj path" of BASELINE config #5.  C = alpha * A . B^T + bias on
  * v_mfma_scale_f32_16x16x128_f8f6f4; epilogue 0 = bf16, 1 = f32, 2 = f32 residual accumulate.  K % 128 == 0;

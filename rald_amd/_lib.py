@@ -100,6 +100,18 @@ SIGNATURES = {
     "rald_op_silu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     "rald_op_posemb": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "rald_op_edm_loss_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rald_op_conv3d": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rald_op_conv_pack_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "rald_op_groupnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "rald_op_groupnorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                      c_int, c_int, c_int, c_void_p]),
+    "rald_op_conv_in": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rald_op_conv_in_wgrad": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rald_op_pad_channels": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_void_p]),
+    "rald_op_zero_insert2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rald_op_im2col_t": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_int, c_void_p]),
+    "rald_op_rowdot": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
+    "rald_op_softmax_rows": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_void_p]),
     "rald_op_gemm_mx8": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_void_p, c_i64, c_i64,
                                  c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "rald_op_quantize_mx8": (c_int, [c_void_p, c_int, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p]),

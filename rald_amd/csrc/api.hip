@@ -291,6 +291,47 @@ int rald_op_edm_loss_grad(const float* F, const float* x_noised, const float* y,
     RALD_CHECK(F && x_noised && y && coef3 && dF && loss, "rald_op_edm_loss_grad: null pointer");
     return edm_loss_grad(F, x_noised, y, coef3, per_sample, total, dF, D_out, loss, (hipStream_t)stream);
 }
+// ---- radar encoder, op level (forward pieces + backward building blocks) --------------------------------------
+int rald_op_conv3d(const void* in_bf16, const void* w_packed_bf16, const float* bias, const float* resid, float* out, int32_t B, int32_t ID,
+                   int32_t IH, int32_t IW, int32_t Cin, int32_t Cout, int32_t stride, int32_t pad, void* stream) {
+    return conv3d_igemm((const bf16*)in_bf16, (const bf16*)w_packed_bf16, bias, resid, out, B, ID, IH, IW, Cin, Cout, stride, pad, (hipStream_t)stream);
+}
+int rald_op_groupnorm(const float* x, const float* gamma, const float* beta, void* y_bf16, double* stats, int32_t B, int32_t S, int32_t C,
+                      int32_t swish, void* stream) {
+    return groupnorm_fwd(x, gamma, beta, (bf16*)y_bf16, stats, B, S, C, swish, (hipStream_t)stream);
+}
+int rald_op_groupnorm_bwd(const float* x, const double* stats, const float* gamma, const float* beta, const float* da, float* dx, float* dgamma,
+                          float* dbeta, double* gsum_scratch, int32_t B, int32_t S, int32_t C, int32_t swish, int32_t accumulate, void* stream) {
+    return groupnorm_bwd(x, stats, gamma, beta, da, dx, dgamma, dbeta, gsum_scratch, B, S, C, swish, accumulate, (hipStream_t)stream);
+}
+int rald_op_conv_in(const float* cube, int32_t cube_ch, int32_t Cin, const float* W, const float* bias, float* out, int32_t B, int32_t D, int32_t H,
+                    int32_t Wd, int32_t Cout, void* stream) {
+    return conv_in_fwd(cube, cube_ch, Cin, W, bias, out, B, D, H, Wd, Cout, (hipStream_t)stream);
+}
+int rald_op_conv_in_wgrad(const float* cube, int32_t cube_ch, const float* dy, int32_t B, int32_t D, int32_t H, int32_t Wd, int32_t Cout, float* dW,
+                          void* stream) {
+    return conv_in_wgrad(cube, cube_ch, dy, B, D, H, Wd, Cout, dW, (hipStream_t)stream);
+}
+int rald_op_conv_pack_weights(const float* W, void* out_bf16, int32_t Cout, int32_t Cin, int32_t pad_to, int32_t dgrad, void* stream) {
+    return conv_pack_weights(W, (bf16*)out_bf16, Cout, Cin, pad_to, dgrad, (hipStream_t)stream);
+}
+int rald_op_pad_channels(const float* x, void* out_bf16, int64_t M, int32_t C, int32_t Cpad, void* stream) {
+    return pad_channels(x, (bf16*)out_bf16, M, C, Cpad, (hipStream_t)stream);
+}
+int rald_op_zero_insert2(const float* dy, void* out_bf16, int32_t B, int32_t OD, int32_t OH, int32_t OW, int32_t C, void* stream) {
+    return zero_insert2(dy, (bf16*)out_bf16, B, OD, OH, OW, C, (hipStream_t)stream);
+}
+int rald_op_im2col_t(const void* x_bf16, void* out_bf16, int32_t B, int32_t ID, int32_t IH, int32_t IW, int32_t C, int32_t stride, int32_t pad,
+                     int64_t m0, int32_t nchunk, void* stream) {
+    return im2col_t((const bf16*)x_bf16, (bf16*)out_bf16, B, ID, IH, IW, C, stride, pad, m0, nchunk, (hipStream_t)stream);
+}
+int rald_op_rowdot(const void* a_bf16, const void* b_bf16, int64_t M, int32_t C, float* out, void* stream) {
+    return rowdot((const bf16*)a_bf16, (const bf16*)b_bf16, M, C, out, (hipStream_t)stream);
+}
+int rald_op_softmax_rows(const float* S, int64_t ld_s, void* P_bf16, int64_t ld_p, int32_t rows, int32_t n, void* stream) {
+    RALD_CHECK(S && P_bf16, "rald_op_softmax_rows: null pointer");
+    return softmax_rows(S, ld_s, (bf16*)P_bf16, ld_p, rows, n, (hipStream_t)stream);
+}
 int rald_op_gemm_mx8(const void* A8, const void* scaleA, int64_t lda, int64_t strideA, int64_t strideSA, const void* B8, const void* scaleB,
                      int64_t ldb, int64_t strideB, int64_t strideSB, void* C, int64_t ldc, int64_t strideC, const float* bias, int32_t M,
                      int32_t N, int32_t K, int32_t batch, float alpha, int32_t epilogue, void* stream) {

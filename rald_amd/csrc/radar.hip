@@ -597,4 +597,45 @@ int RadarEncoder::tokens(const float* cube, int B, float** tokens_out, hipStream
 
 RadarEncoder::~RadarEncoder() { delete impl; }
 
+// ---- op-level launchers of the kernels above (used by the training path, radar_train.hip / train_encoder.py) ------
+int conv3d_igemm(const bf16* in, const bf16* w_packed, const float* bias, const float* resid, float* out, int B, int ID, int IH, int IW,
+                 int Cin, int Cout, int stride, int pad, hipStream_t st) {
+    RALD_CHECK(in && w_packed && bias && out, "conv3d: null pointer");
+    RALD_CHECK(B > 0 && ID > 0 && IH > 0 && IW > 0 && (stride == 1 || stride == 2), "conv3d: bad geometry");
+    RALD_CHECK(Cin % 64 == 0 && Cout % 4 == 0, "conv3d: Cin must be a multiple of 64 and Cout of 4");
+    ConvArgs a;
+    a.in = in; a.w = w_packed; a.bias = bias; a.resid = resid; a.out = out;
+    a.B = B; a.ID = ID; a.IH = IH; a.IW = IW; a.Cin = Cin; a.Cout = Cout; a.stride = stride; a.pad = pad;
+    a.OD = ID / stride; a.OH = IH / stride; a.OW = IW / stride;
+    const int64_t M = (int64_t)B * a.OD * a.OH * a.OW;
+    hipLaunchKernelGGL(conv3d_igemm_kernel, dim3(cdiv(Cout, 64), (unsigned)((M + 127) / 128)), dim3(256), 0, st, a);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+int groupnorm_fwd(const float* x, const float* gamma, const float* beta, bf16* y, double* stats, int B, int S, int C, int swish,
+                  hipStream_t st) {
+    RALD_CHECK(x && gamma && beta && y && stats, "groupnorm: null pointer");
+    RALD_CHECK(B > 0 && S > 0 && C % 64 == 0 && 256 % (C / 4) == 0, "groupnorm: channel count must be 64, 128 or 256");
+    RALD_HIP(hipMemsetAsync(stats, 0, (size_t)B * 32 * 2 * 8, st));
+    const int vpb = 2048;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(cdiv(S, vpb), B), dim3(256), 0, st, x, stats, S, C, vpb);
+    const int64_t quads = (int64_t)S * C / 4;
+    const int blocks = (int)((quads + 255) / 256 < 1024 ? (quads + 255) / 256 : 1024);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, B), dim3(256), 0, st, x, stats, gamma, beta, y, S, C, 1e-6f, swish ? 1 : 0);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+int conv_in_fwd(const float* cube, int cube_ch, int Cin, const float* W, const float* bias, float* out, int B, int D, int H, int Wd, int Cout,
+                hipStream_t st) {
+    RALD_CHECK(cube && W && bias && out && Cout % 8 == 0 && 256 % (Cout / 8) == 0 && cube_ch >= Cin, "conv_in: bad arguments");
+    const int groups = Cout / 8, vpb = 256 / groups;
+    const int64_t nvox = (int64_t)B * D * H * Wd;
+    hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)((nvox + vpb - 1) / vpb)), dim3(256), Cin * 27 * Cout * 4, st, cube, cube_ch, Cin, W, bias, out,
+                       B, D, H, Wd, Cout);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace rald

@@ -1,0 +1,269 @@
+// Backward-pass building blocks of the radar-spectrum encoder (model/models_radar_encoder.py:29-241; the shipped
+// configuration trains it jointly with the denoiser, `unfreeze_radar_enc: true`).  Layout as in radar.hip:
+// activations channels-last [b][d][h][w][c], fp32 trunk, bf16 conv inputs.
+//   * Conv3d data gradient = the forward implicit-GEMM kernel on dY with flipped, transposed weights
+//     (conv_pack_weights with dgrad = 1); the stride-2 Downsample's gradient first spreads dY onto the even
+//     positions of a zero grid (zero_insert2) and then runs the same stride-1 kernel with pad 2.
+//   * Conv3d weight gradient = one MFMA GEMM per voxel chunk: dW[co][ci*27+t] += dY^T[co][m] . patches^T[ci*27+t][m],
+//     with the transposed im2col matrix written by im2col_t (rows in the weight tensor's own order, so the result
+//     accumulates straight into the fp32 gradient of the [Cout, Cin, 3, 3, 3] parameter).
+//   * GroupNorm(32 groups, eps 1e-6) + swish backward in two streaming passes (group sums, then dx).
+#include "common.h"
+#include "kernels.h"
+
+namespace rald {
+
+// W [Cout][Cin][27] fp32 (the parameter's layout) -> packed bf16 for conv3d_igemm.
+//   forward: out[co][t][ci]  (ci < Cin_pad; zero beyond Cin)
+//   dgrad  : out[ci][t][co] = W[co][ci][26 - t]  (co < Cout_pad; zero beyond Cout) - the kernel then maps dY -> dX
+__global__ void conv_pack_weights_kernel(const float* __restrict__ W, bf16* __restrict__ out, int Cout, int Cin, int pad_to, int dgrad, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int inner = (int)(i % pad_to);
+    const int t = (int)((i / pad_to) % 27);
+    const int outer = (int)(i / ((int64_t)pad_to * 27));
+    float v = 0.f;
+    if (!dgrad) { if (inner < Cin) v = W[((int64_t)outer * Cin + inner) * 27 + t]; }
+    else { if (inner < Cout) v = W[((int64_t)inner * Cin + outer) * 27 + (26 - t)]; }
+    out[i] = (bf16)v;
+}
+int conv_pack_weights(const float* W, bf16* out, int Cout, int Cin, int pad_to, int dgrad, hipStream_t st) {
+    RALD_CHECK(W && out && Cout > 0 && Cin > 0 && pad_to >= (dgrad ? Cout : Cin), "conv_pack_weights: bad arguments");
+    const int64_t total = (int64_t)(dgrad ? Cin : Cout) * 27 * pad_to;
+    hipLaunchKernelGGL(conv_pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, out, Cout, Cin, pad_to, dgrad, total);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+// x [M][C] f32 -> bf16 [M][Cpad], zero-filled channels (conv_out has 16 output channels, the kernel wants 64 inputs)
+__global__ void pad_channels_kernel(const float* __restrict__ x, bf16* __restrict__ out, int C, int Cpad, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % Cpad);
+    out[i] = (bf16)(c < C ? x[(i / Cpad) * C + c] : 0.f);
+}
+int pad_channels(const float* x, bf16* out, int64_t M, int C, int Cpad, hipStream_t st) {
+    RALD_CHECK(x && out && M > 0 && C > 0 && Cpad >= C, "pad_channels: bad arguments");
+    const int64_t total = M * Cpad;
+    hipLaunchKernelGGL(pad_channels_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, out, C, Cpad, total);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+// dY [B][OD][OH][OW][C] f32 -> bf16 [B][2OD][2OH][2OW][C] with dY on the even positions, zeros elsewhere
+__global__ void zero_insert2_kernel(const float* __restrict__ dy, bf16* __restrict__ out, int OD, int OH, int OW, int C, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    int64_t r = i / C;
+    const int w = (int)(r % (2 * OW)); r /= 2 * OW;
+    const int h = (int)(r % (2 * OH)); r /= 2 * OH;
+    const int d = (int)(r % (2 * OD));
+    const int64_t b = r / (2 * OD);
+    float v = 0.f;
+    if (!((w | h | d) & 1)) v = dy[((((b * OD + d / 2) * OH + h / 2) * OW + w / 2)) * C + c];
+    out[i] = (bf16)v;
+}
+int zero_insert2(const float* dy, bf16* out, int B, int OD, int OH, int OW, int C, hipStream_t st) {
+    RALD_CHECK(dy && out && B > 0 && OD > 0 && OH > 0 && OW > 0 && C > 0, "zero_insert2: bad arguments");
+    const int64_t total = (int64_t)B * 8 * OD * OH * OW * C;
+    hipLaunchKernelGGL(zero_insert2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, out, OD, OH, OW, C, total);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+// Transposed im2col of a chunk of output voxels: out[(ci*27 + t)][j] = x[b][od*s - p + kd][..][ci] for output voxel
+// m0 + j (zero outside the volume).  One 64-voxel x 64-channel tile per (blockIdx.x, tap, channel block), through LDS.
+__global__ __launch_bounds__(256) void im2col_t_kernel(const bf16* __restrict__ x, bf16* __restrict__ out, int ID, int IH, int IW, int C, int OD, int OH,
+                                                       int OW, int stride, int pad, int64_t m0, int nchunk, int64_t Mtot) {
+    __shared__ bf16 tile[64][72];
+    const int j0 = blockIdx.x * 64, tap = blockIdx.y, c0 = blockIdx.z * 64;
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    for (int p = 0; p < 2; ++p) {
+        const int jr = (threadIdx.x >> 3) + 32 * p, cc = (threadIdx.x & 7) * 8;
+        bf16x8 v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (bf16)0.f;
+        const int64_t m = m0 + j0 + jr;
+        if (j0 + jr < nchunk && m < Mtot) {
+            const int ow = (int)(m % OW);
+            int64_t r = m / OW;
+            const int oh = (int)(r % OH); r /= OH;
+            const int od = (int)(r % OD);
+            const int64_t b = r / OD;
+            const int id = od * stride - pad + kd, ih = oh * stride - pad + kh, iw = ow * stride - pad + kw;
+            if ((unsigned)id < (unsigned)ID && (unsigned)ih < (unsigned)IH && (unsigned)iw < (unsigned)IW)
+                v = *reinterpret_cast<const bf16x8*>(x + ((((b * ID + id) * IH + ih) * IW + iw)) * C + c0 + cc);
+        }
+        *reinterpret_cast<bf16x8*>(&tile[jr][cc]) = v;
+    }
+    __syncthreads();
+    for (int p = 0; p < 2; ++p) {
+        const int c = (threadIdx.x >> 3) + 32 * p, jr = (threadIdx.x & 7) * 8;
+        if (j0 + jr < nchunk) {
+            bf16x8 v;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = tile[jr + i][c];
+            *reinterpret_cast<bf16x8*>(out + ((int64_t)(c0 + c) * 27 + tap) * nchunk + j0 + jr) = v;
+        }
+    }
+}
+int im2col_t(const bf16* x, bf16* out, int B, int ID, int IH, int IW, int C, int stride, int pad, int64_t m0, int nchunk, hipStream_t st) {
+    RALD_CHECK(x && out && C % 64 == 0 && nchunk > 0 && nchunk % 8 == 0, "im2col_t: C must be a multiple of 64 and the chunk of 8");
+    const int OD = ID / stride, OH = IH / stride, OW = IW / stride;
+    const int64_t Mtot = (int64_t)B * OD * OH * OW;
+    RALD_CHECK(m0 >= 0 && m0 < Mtot, "im2col_t: chunk start out of range");
+    hipLaunchKernelGGL(im2col_t_kernel, dim3(cdiv(nchunk, 64), 27, C / 64), dim3(256), 0, st, x, out, ID, IH, IW, C, OD, OH, OW, stride, pad, m0, nchunk,
+                       Mtot);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+// conv_in (Cin = 1): dW[co][t] += sum_v dY[v][co] * cube[v + off(t)][0]; one block per 256 voxels, Cout <= 64
+__global__ __launch_bounds__(256) void conv_in_wgrad_kernel(const float* __restrict__ cube, int cube_ch, const float* __restrict__ dy, int B, int D, int H,
+                                                            int Wd, int Cout, float* __restrict__ dW) {
+    __shared__ float sx[256][28];
+    const int64_t nvox = (int64_t)B * D * H * Wd;
+    const int64_t v0 = (int64_t)blockIdx.x * 256;
+    {
+        const int64_t v = v0 + threadIdx.x;
+        int w = 0, h = 0, d = 0;
+        int64_t b = 0;
+        if (v < nvox) { w = (int)(v % Wd); int64_t r = v / Wd; h = (int)(r % H); r /= H; d = (int)(r % D); b = r / D; }
+        for (int t = 0; t < 27; ++t) {
+            const int id = d + t / 9 - 1, ih = h + (t / 3) % 3 - 1, iw = w + t % 3 - 1;
+            float x = 0.f;
+            if (v < nvox && (unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)Wd)
+                x = cube[((((b * D + id) * H + ih) * Wd + iw)) * cube_ch];
+            sx[threadIdx.x][t] = x;
+        }
+    }
+    __syncthreads();
+    // thread -> (co = tid % 64, tap group = tid / 64: taps g, g+4, ...)
+    const int co = threadIdx.x & 63, g = threadIdx.x >> 6;
+    if (co >= Cout) return;
+    float acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    const int64_t vend = nvox - v0 < 256 ? nvox - v0 : 256;
+    for (int j = 0; j < (int)vend; ++j) {
+        const float g_ = dy[(v0 + j) * Cout + co];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) { const int t = g + 4 * q; if (t < 27) acc[q] += g_ * sx[j][t]; }
+    }
+#pragma unroll
+    for (int q = 0; q < 7; ++q) { const int t = g + 4 * q; if (t < 27) atomicAdd(dW + co * 27 + t, acc[q]); }
+}
+int conv_in_wgrad(const float* cube, int cube_ch, const float* dy, int B, int D, int H, int Wd, int Cout, float* dW, hipStream_t st) {
+    RALD_CHECK(cube && dy && dW && Cout <= 64, "conv_in_wgrad: Cout must be <= 64");
+    const int64_t nvox = (int64_t)B * D * H * Wd;
+    hipLaunchKernelGGL(conv_in_wgrad_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, cube, cube_ch, dy, B, D, H, Wd, Cout, dW);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- GroupNorm (+ swish) backward -------------------------------------------------------------------------------
+// forward: y = xhat * gamma + beta (xhat over the group's S*cpg elements), a = swish(y) or y.  Given da:
+//   pass 1: dgamma[c] += sum dy*xhat, dbeta[c] += sum dy, gsum[b][g] += {sum dy*gamma, sum dy*gamma*xhat}
+//   pass 2: dx (+)= rstd * (dy*gamma - gsum0/n - xhat * gsum1/n)
+struct GnBwdArgs {
+    const float* x; const double* stats; const float* gamma; const float* beta; const float* da;
+    float* dx; float* dgamma; float* dbeta; double* gsum;
+    int S, C, swish, accumulate; float eps;
+};
+__device__ __forceinline__ float gn_dy(float yv, float da, int swish) {
+    if (!swish) return da;
+    const float sg = 1.0f / (1.0f + __expf(-yv));
+    return da * sg * (1.0f + yv * (1.0f - sg));
+}
+__global__ __launch_bounds__(256) void gn_bwd_pass_kernel(GnBwdArgs a, int pass, int vox_per_block) {
+    __shared__ float smean[32], srstd[32], sm1[32], sm2[32];
+    __shared__ float cacc[2][256];                          // per-channel partials (C <= 256)
+    __shared__ float gacc[2][32];
+    const int b = blockIdx.y, C = a.C, cpg = C / 32, quads = C / 4;
+    if (threadIdx.x < 32) {
+        const double n = (double)a.S * cpg;
+        const double su = a.stats[((int64_t)b * 32 + threadIdx.x) * 2], sq = a.stats[((int64_t)b * 32 + threadIdx.x) * 2 + 1];
+        const double mean = su / n, var = sq / n - mean * mean;
+        smean[threadIdx.x] = (float)mean;
+        srstd[threadIdx.x] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)a.eps));
+        if (pass == 2) {
+            sm1[threadIdx.x] = (float)(a.gsum[((int64_t)b * 32 + threadIdx.x) * 2] / n);
+            sm2[threadIdx.x] = (float)(a.gsum[((int64_t)b * 32 + threadIdx.x) * 2 + 1] / n);
+        }
+        gacc[0][threadIdx.x] = 0.f; gacc[1][threadIdx.x] = 0.f;
+    }
+    cacc[0][threadIdx.x] = 0.f; cacc[1][threadIdx.x] = 0.f;
+    __syncthreads();
+    const int q = threadIdx.x % quads, vstep = 256 / quads;
+    const int v0 = blockIdx.x * vox_per_block, v1 = min(a.S, v0 + vox_per_block);
+    const float4 gm = reinterpret_cast<const float4*>(a.gamma)[q], bt = reinterpret_cast<const float4*>(a.beta)[q];
+    const float gg[4] = {gm.x, gm.y, gm.z, gm.w}, bb[4] = {bt.x, bt.y, bt.z, bt.w};
+    float pg[4] = {0, 0, 0, 0}, pb[4] = {0, 0, 0, 0}, g1[4] = {0, 0, 0, 0}, g2[4] = {0, 0, 0, 0};
+    for (int v = v0 + threadIdx.x / quads; v < v1; v += vstep) {
+        const int64_t idx = ((int64_t)b * a.S + v) * quads + q;
+        const float4 t = reinterpret_cast<const float4*>(a.x)[idx], d = reinterpret_cast<const float4*>(a.da)[idx];
+        const float xv[4] = {t.x, t.y, t.z, t.w}, dv[4] = {d.x, d.y, d.z, d.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int g = (4 * q + j) / cpg;
+            const float xh = (xv[j] - smean[g]) * srstd[g];
+            const float dy = gn_dy(xh * gg[j] + bb[j], dv[j], a.swish);
+            if (pass == 1) { pg[j] += dy * xh; pb[j] += dy; g1[j] += dy * gg[j]; g2[j] += dy * gg[j] * xh; }
+            else o[j] = srstd[g] * (dy * gg[j] - sm1[g] - xh * sm2[g]);
+        }
+        if (pass == 2) {
+            float4* dst = reinterpret_cast<float4*>(a.dx) + idx;
+            float4 r = a.accumulate ? *dst : make_float4(0.f, 0.f, 0.f, 0.f);
+            r.x += o[0]; r.y += o[1]; r.z += o[2]; r.w += o[3];
+            *dst = r;
+        }
+    }
+    if (pass == 2) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        atomicAdd(&cacc[0][4 * q + j], pg[j]);
+        atomicAdd(&cacc[1][4 * q + j], pb[j]);
+        const int g = (4 * q + j) / cpg;
+        atomicAdd(&gacc[0][g], g1[j]);
+        atomicAdd(&gacc[1][g], g2[j]);
+    }
+    __syncthreads();
+    if (threadIdx.x < C) { atomicAdd(a.dgamma + threadIdx.x, cacc[0][threadIdx.x]); atomicAdd(a.dbeta + threadIdx.x, cacc[1][threadIdx.x]); }
+    if (threadIdx.x < 32) {
+        atomicAdd(&a.gsum[((int64_t)b * 32 + threadIdx.x) * 2], (double)gacc[0][threadIdx.x]);
+        atomicAdd(&a.gsum[((int64_t)b * 32 + threadIdx.x) * 2 + 1], (double)gacc[1][threadIdx.x]);
+    }
+}
+int groupnorm_bwd(const float* x, const double* stats, const float* gamma, const float* beta, const float* da, float* dx, float* dgamma, float* dbeta,
+                  double* gsum_scratch, int B, int S, int C, int swish, int accumulate, hipStream_t st) {
+    RALD_CHECK(x && stats && gamma && beta && da && dx && dgamma && dbeta && gsum_scratch, "groupnorm_bwd: null pointer");
+    RALD_CHECK(B > 0 && S > 0 && C % 64 == 0 && C <= 256 && 256 % (C / 4) == 0, "groupnorm_bwd: channel count must be 64, 128 or 256");
+    GnBwdArgs a;
+    a.x = x; a.stats = stats; a.gamma = gamma; a.beta = beta; a.da = da; a.dx = dx; a.dgamma = dgamma; a.dbeta = dbeta; a.gsum = gsum_scratch;
+    a.S = S; a.C = C; a.swish = swish; a.accumulate = accumulate; a.eps = 1e-6f;
+    RALD_HIP(hipMemsetAsync(gsum_scratch, 0, (size_t)B * 32 * 2 * 8, st));
+    const int vpb = 1024;
+    hipLaunchKernelGGL(gn_bwd_pass_kernel, dim3(cdiv(S, vpb), B), dim3(256), 0, st, a, 1, vpb);
+    hipLaunchKernelGGL(gn_bwd_pass_kernel, dim3(cdiv(S, vpb), B), dim3(256), 0, st, a, 2, vpb);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+// delta[m] = sum_c a[m][c] * b[m][c]  (bf16 rows of any width; the single-head attention of AttnBlock :102-135)
+__global__ __launch_bounds__(256) void rowdot_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, int64_t M, int C, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += (float)a[row * C + c] * (float)b[row * C + c];
+    s = wave_sum(s);
+    if (lane == 0) out[row] = s;
+}
+int rowdot(const bf16* a, const bf16* b, int64_t M, int C, float* out, hipStream_t st) {
+    RALD_CHECK(a && b && out && M > 0 && C > 0, "rowdot: bad arguments");
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, a, b, M, C, out);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace rald

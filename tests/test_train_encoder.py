@@ -1,0 +1,84 @@
+"""Backward building blocks of the radar-spectrum encoder (models_radar_encoder.py:29-241)
+against torch autograd on the CPU: Conv3d forward / data gradient / weight gradient (stride 1 and the Downsample
+form F.pad(0,1) + k3 s2), GroupNorm(32, eps 1e-6)(+swish) forward / backward.  bf16 MFMA operands, fp32
+accumulation: rel-L2 <= 1e-2 against fp32 math on the same (bf16-rounded where the kernel rounds) inputs."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+from rald_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _cl(t):      # NCDHW -> channels-last NDHWC contiguous
+    return t.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _cf(t):      # NDHWC -> NCDHW
+    return t.permute(0, 4, 1, 2, 3).contiguous()
+
+
+def test_conv3d_forward_dgrad_wgrad_vs_autograd():
+    from rald_amd import train_encoder as TE
+    for (B, D, H, W, Cin, Cout) in ((2, 8, 6, 4, 64, 128), (1, 4, 4, 8, 128, 16)):
+        x = synth.normal([B, Cin, D, H, W], 600).bfloat16().float().requires_grad_()
+        Wt = (synth.normal([Cout, Cin, 3, 3, 3], 601) / (Cin * 27) ** 0.5).requires_grad_()
+        b = synth.normal([Cout], 602) * 0.1
+        y = F.conv3d(x, Wt.detach().bfloat16().float() + (Wt - Wt.detach()), b, padding=1)     # forward on the bf16-rounded weights, gradient to Wt
+        dy = synth.normal([B, Cout, D, H, W], 603)
+        y.backward(dy)
+        x16 = _cl(x.detach()).bfloat16().cuda()
+        out = TE.conv3d(x16, TE.pack_conv(Wt.detach().cuda()), b.cuda())
+        assert rel_l2(_cf(out.cpu()), y.detach()) < 3e-3
+        dx = TE.conv_dgrad(_cl(dy).cuda(), Wt.detach().cuda())
+        print("conv dgrad rel_l2", rel_l2(_cf(dx.cpu()), x.grad))
+        assert rel_l2(_cf(dx.cpu()), x.grad) < 1e-2
+        dW, db = torch.zeros_like(Wt, device="cuda"), torch.zeros(Cout, device="cuda")
+        TE.conv_wgrad(_cl(dy).cuda(), x16, dW, db)
+        print("conv wgrad rel_l2", rel_l2(dW.cpu(), Wt.grad), rel_l2(db.cpu(), dy.sum((0, 2, 3, 4))))
+        assert rel_l2(dW.cpu(), Wt.grad) < 1e-2 and rel_l2(db.cpu(), dy.sum((0, 2, 3, 4))) < 1e-5
+
+
+def test_downsample_forward_dgrad_wgrad_vs_autograd():
+    from rald_amd import train_encoder as TE
+    B, D, H, W, Cc = 2, 8, 4, 4, 64
+    x = synth.normal([B, Cc, D, H, W], 610).bfloat16().float().requires_grad_()
+    Wt = (synth.normal([Cc, Cc, 3, 3, 3], 611) / (Cc * 27) ** 0.5).requires_grad_()
+    b = synth.normal([Cc], 612) * 0.1
+    y = F.conv3d(F.pad(x, (0, 1, 0, 1, 0, 1)), Wt.detach().bfloat16().float() + (Wt - Wt.detach()), b, stride=2)      # Downsample.forward :37-41
+    dy = synth.normal(list(y.shape), 613)
+    y.backward(dy)
+    x16 = _cl(x.detach()).bfloat16().cuda()
+    out = TE.conv3d(x16, TE.pack_conv(Wt.detach().cuda()), b.cuda(), stride=2, pad=0)
+    assert out.shape == (B, D // 2, H // 2, W // 2, Cc)
+    assert rel_l2(_cf(out.cpu()), y.detach()) < 3e-3
+    dx = TE.down_dgrad(_cl(dy).cuda(), Wt.detach().cuda())
+    print("downsample dgrad rel_l2", rel_l2(_cf(dx.cpu()), x.grad))
+    assert rel_l2(_cf(dx.cpu()), x.grad) < 1e-2
+    dW = torch.zeros_like(Wt, device="cuda")
+    TE.conv_wgrad(_cl(dy).cuda(), x16, dW, None, stride=2, pad=0)
+    print("downsample wgrad rel_l2", rel_l2(dW.cpu(), Wt.grad))
+    assert rel_l2(dW.cpu(), Wt.grad) < 1e-2
+
+
+def test_groupnorm_swish_forward_backward_vs_autograd():
+    from rald_amd import train_encoder as TE
+    for Cc, swish in ((64, True), (128, False), (256, True)):
+        B, D, H, W = 2, 8, 4, 2
+        x = (synth.normal([B, Cc, D, H, W], 620) * 1.7 + 0.4).requires_grad_()
+        g, b = (1 + 0.1 * synth.normal([Cc], 621)).requires_grad_(), (0.1 * synth.normal([Cc], 622)).requires_grad_()
+        y = F.group_norm(x, 32, g, b, eps=1e-6)
+        a = y * torch.sigmoid(y) if swish else y
+        da = synth.normal(list(a.shape), 623)
+        a.backward(da)
+        xc = _cl(x.detach()).cuda()
+        y16, stats = TE.groupnorm(xc, g.detach().cuda(), b.detach().cuda(), swish)
+        assert rel_l2(_cf(y16.float().cpu()), a.detach()) < 4e-3
+        dx = torch.ones_like(xc)
+        dg, db = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+        TE.groupnorm_bwd(xc, stats, g.detach().cuda(), b.detach().cuda(), _cl(da).cuda(), dx, dg, db, swish, accumulate=True)
+        e = (rel_l2(_cf(dx.cpu()) - 1, x.grad), rel_l2(dg.cpu(), g.grad), rel_l2(db.cpu(), b.grad))
+        print(f"groupnorm C={Cc} swish={swish}: dx {e[0]:.2e} dgamma {e[1]:.2e} dbeta {e[2]:.2e}")
+        assert max(e) < 1e-4
