@@ -112,3 +112,218 @@ def conv_wgrad(dy: torch.Tensor, x16: torch.Tensor, dW: torch.Tensor, dbias: Opt
         op_gemm_nt(TO.T2(rows), col, epilogue=2, C_inout=dW2)
     if dbias is not None:
         TO.colsum(dy2, dbias)
+
+
+def _g(p: torch.nn.Parameter) -> torch.Tensor:
+    if p.grad is None:
+        p.grad = torch.zeros_like(p.data)
+    return p.grad
+
+
+def _sgemm(A, B, out, trans_a=False, trans_b=False):
+    M = A.shape[1] if trans_a else A.shape[0]
+    K = A.shape[0] if trans_a else A.shape[1]
+    N = B.shape[1] if trans_b else B.shape[0]
+    check(lib().rald_op_sgemm_acc(_p(A), A.stride(0), int(trans_a), _p(B), B.stride(0), int(trans_b), _p(out), out.stride(0), M, N, K, 1.0, _st()))
+    return out
+
+
+class EncoderTrainer:
+    """Forward with saved activations + backward of ``Encoder`` (ch 64, ch_mult (1,1,2,2,4), 2 res blocks, attention at the
+    last level, z channels 16) and of the tokeniser (radar_token_project + r/a/e embeddings).  ``named_params``: the
+    parameters by their EDMPrecond state-dict names (``radar_enc.*``, ``radar_token_project.*``, ``radar_{r,a,e}_emb.weight``);
+    gradients are accumulated into ``param.grad``."""
+
+    def __init__(self, named_params: Dict[str, torch.nn.Parameter], ch: int = 64, prefix: str = "radar_enc."):
+        self.P, self.ch, self.pre = named_params, ch, prefix
+        self.dev = next(iter(named_params.values())).device
+        if self.dev.type != "cuda":
+            raise RuntimeError("EncoderTrainer runs on the HIP device only (no CPU fallback)")
+        self.saved: List = []
+
+    def p(self, name: str) -> torch.nn.Parameter:
+        return self.P[self.pre + name]
+
+    def w(self, name: str) -> torch.Tensor:
+        return self.p(name).data
+
+    # ---- ResnetBlock :46-100 ---------------------------------------------------------------------------------------
+    def _res_fwd(self, x, name, cin, cout):
+        h1, st1 = groupnorm(x, self.w(name + ".norm1.weight"), self.w(name + ".norm1.bias"), True)
+        t1 = conv3d(h1, pack_conv(self.w(name + ".conv1.weight")), self.w(name + ".conv1.bias"))
+        del h1
+        h2, st2 = groupnorm(t1, self.w(name + ".norm2.weight"), self.w(name + ".norm2.bias"), True)
+        res = x
+        if cin != cout:
+            x16 = TO.cast_bf16(x)
+            res = op_gemm_nt(x16.view(-1, cin), self.w(name + ".nin_shortcut.weight").view(cout, cin).to(torch.bfloat16),
+                             bias=self.w(name + ".nin_shortcut.bias"), epilogue=1).view(*x.shape[:-1], cout)
+        out = conv3d(h2, pack_conv(self.w(name + ".conv2.weight")), self.w(name + ".conv2.bias"), resid=res)
+        self.saved.append(("res", name, cin, cout, x, st1, t1, st2))
+        return out
+
+    def _res_bwd(self, rec, dout):
+        _, name, cin, cout, x, st1, t1, st2 = rec
+        P = lambda n: self.p(name + n)
+        h2, _ = groupnorm(t1, P(".norm2.weight").data, P(".norm2.bias").data, True)
+        conv_wgrad(dout, h2, _g(P(".conv2.weight")), _g(P(".conv2.bias")))
+        del h2
+        dh2 = conv_dgrad(dout, P(".conv2.weight").data)
+        dt1 = torch.empty_like(t1)
+        groupnorm_bwd(t1, st2, P(".norm2.weight").data, P(".norm2.bias").data, dh2, dt1, _g(P(".norm2.weight")), _g(P(".norm2.bias")), True, False)
+        del dh2
+        h1, _ = groupnorm(x, P(".norm1.weight").data, P(".norm1.bias").data, True)
+        conv_wgrad(dt1, h1, _g(P(".conv1.weight")), _g(P(".conv1.bias")))
+        del h1
+        dh1 = conv_dgrad(dt1, P(".conv1.weight").data)
+        if cin == cout:
+            dx = dout
+        else:
+            d2 = dout.view(-1, cout)
+            W16 = P(".nin_shortcut.weight").data.view(cout, cin).to(torch.bfloat16)
+            dx = op_gemm_nt(TO.cast_bf16(d2), TO.T2(W16), epilogue=1).view(*x.shape)
+            op_gemm_nt(TO.T2(d2), TO.T2(TO.cast_bf16(x).view(-1, cin)), epilogue=2, C_inout=_g(P(".nin_shortcut.weight")).view(cout, cin))
+            TO.colsum(d2, _g(P(".nin_shortcut.bias")))
+        groupnorm_bwd(x, st1, P(".norm1.weight").data, P(".norm1.bias").data, dh1, dx, _g(P(".norm1.weight")), _g(P(".norm1.bias")), True, True)
+        return dx
+
+    # ---- AttnBlock :102-135 (single head, S tokens, scale C^-1/2) -----------------------------------------------------
+    def _attn_fwd(self, x, name):
+        B, Cc = x.shape[0], x.shape[-1]
+        S = x.numel() // (B * Cc)
+        W16 = lambda n: self.w(name + n).view(Cc, Cc).to(torch.bfloat16)
+        n16, st = groupnorm(x, self.w(name + ".norm.weight"), self.w(name + ".norm.bias"), False)
+        n2 = n16.view(B * S, Cc)
+        q = op_gemm_nt(n2, W16(".q.weight"), bias=self.w(name + ".q.bias"))
+        k = op_gemm_nt(n2, W16(".k.weight"), bias=self.w(name + ".k.bias"))
+        v = op_gemm_nt(n2, W16(".v.weight"), bias=self.w(name + ".v.bias"))
+        scale = float(Cc) ** -0.5
+        Sm = torch.empty(B, S, S, device=x.device, dtype=torch.float32)
+        TO.gemm2(q, Cc, S * Cc, 0, k, Cc, S * Cc, 0, Sm, S, S * S, 0, S, S, Cc, B, 1, epilogue=1)
+        lse = torch.empty(B, S, device=x.device, dtype=torch.float32)
+        check(lib().rald_op_row_lse(_p(Sm), B * S, S, scale, _p(lse), _st()))
+        Pm = torch.empty(B, S, S, device=x.device, dtype=torch.bfloat16)
+        Ssc = Sm * scale                                                # [B,64,64]: tiny
+        check(lib().rald_op_softmax_rows(_p(Ssc), S, _p(Pm), S, B * S, S, _st()))
+        vT = TO.transpose(v, S, Cc, Cc, B, S * Cc).view(B, Cc, S)
+        o = torch.empty(B * S, Cc, device=x.device, dtype=torch.bfloat16)
+        TO.gemm2(Pm, S, S * S, 0, vT, S, Cc * S, 0, o, Cc, S * Cc, 0, S, Cc, S, B, 1)
+        out = x.clone()
+        op_gemm_nt(o, W16(".proj_out.weight"), bias=self.w(name + ".proj_out.bias"), epilogue=2, C_inout=out.view(B * S, Cc))
+        self.saved.append(("attn", name, x, st, q, k, v, Sm, lse, Pm, o))
+        return out
+
+    def _attn_bwd(self, rec, dxo):
+        _, name, x, st, q, k, v, Sm, lse, Pm, o = rec
+        B, Cc = x.shape[0], x.shape[-1]
+        S = x.numel() // (B * Cc)
+        P = lambda n: self.p(name + n)
+        W16 = lambda n: P(n).data.view(Cc, Cc).to(torch.bfloat16)
+        scale = float(Cc) ** -0.5
+        d2 = dxo.view(B * S, Cc)
+        n16, _ = groupnorm(x, P(".norm.weight").data, P(".norm.bias").data, False)
+        n2 = n16.view(B * S, Cc)
+        do = op_gemm_nt(TO.cast_bf16(d2), TO.T2(W16(".proj_out.weight")))                       # [B*S, C] bf16
+        op_gemm_nt(TO.T2(d2), TO.T2(o), epilogue=2, C_inout=_g(P(".proj_out.weight")).view(Cc, Cc))
+        TO.colsum(d2, _g(P(".proj_out.bias")))
+        dP = torch.empty(B, S, S, device=x.device, dtype=torch.float32)
+        TO.gemm2(do, Cc, S * Cc, 0, v, Cc, S * Cc, 0, dP, S, S * S, 0, S, S, Cc, B, 1, epilogue=1)
+        delta = torch.empty(B, S, device=x.device, dtype=torch.float32)
+        check(lib().rald_op_rowdot(_p(do), _p(o), B * S, Cc, _p(delta), _st()))
+        dS = torch.empty(B, S, S, device=x.device, dtype=torch.bfloat16)
+        check(lib().rald_op_attn_bwd_elem(_p(Sm), _p(dP), _p(lse), _p(delta), B, S, S, S, 1, scale, 0, _p(None), _p(dS), _st()))
+        tb = lambda t, r, c: TO.transpose(t, r, c, c, B, r * c).view(B, c, r)                  # per-sample transpose
+        dq = torch.empty(B * S, Cc, device=x.device, dtype=torch.bfloat16)
+        dk, dv = torch.empty_like(dq), torch.empty_like(dq)
+        TO.gemm2(dS, S, S * S, 0, tb(k, S, Cc), S, Cc * S, 0, dq, Cc, S * Cc, 0, S, Cc, S, B, 1)              # dS . k
+        TO.gemm2(tb(dS, S, S), S, S * S, 0, tb(q, S, Cc), S, Cc * S, 0, dk, Cc, S * Cc, 0, S, Cc, S, B, 1)    # dS^T . q
+        TO.gemm2(tb(Pm, S, S), S, S * S, 0, tb(do, S, Cc), S, Cc * S, 0, dv, Cc, S * Cc, 0, S, Cc, S, B, 1)   # P^T . do
+        dn = op_gemm_nt(dq, TO.T2(W16(".q.weight")), epilogue=1)
+        op_gemm_nt(dk, TO.T2(W16(".k.weight")), epilogue=2, C_inout=dn)
+        op_gemm_nt(dv, TO.T2(W16(".v.weight")), epilogue=2, C_inout=dn)
+        n2T = TO.T2(n2)
+        for g, nm in ((dq, ".q"), (dk, ".k"), (dv, ".v")):
+            op_gemm_nt(TO.T2(g), n2T, epilogue=2, C_inout=_g(P(nm + ".weight")).view(Cc, Cc))
+            TO.colsum(g, _g(P(nm + ".bias")))
+        dx = dxo                                                                         # residual path
+        groupnorm_bwd(x, st, P(".norm.weight").data, P(".norm.bias").data, dn.view(*x.shape), dx, _g(P(".norm.weight")), _g(P(".norm.bias")),
+                      False, True)
+        return dx
+
+    # ---- Encoder.forward :216-241 + tokeniser (models_radar_generation.py:363-407) -------------------------------------
+    def forward(self, cube: torch.Tensor) -> torch.Tensor:
+        """cube [B, R, A, E, cube_ch] f32 -> condition tokens [B, R/16*A/16*E/16, 512] f32 (activations saved for backward)."""
+        self.saved = []
+        B, R, A, E, cch = cube.shape
+        ch = self.ch
+        cube = cube.contiguous()
+        x = torch.empty(B, R, A, E, ch, device=self.dev, dtype=torch.float32)
+        check(lib().rald_op_conv_in(_p(cube), cch, 1, _p(self.w("conv_in.weight")), _p(self.w("conv_in.bias")), _p(x), B, R, A, E, ch, _st()))
+        self.saved.append(("conv_in", cube))
+        cin = ch
+        for l in range(5):
+            cout = ch * CH_MULT[l]
+            for b in range(2):
+                x = self._res_fwd(x, f"down.{l}.block.{b}", cin, cout)
+                cin = cout
+                if l == 4:
+                    x = self._attn_fwd(x, f"down.{l}.attn.{b}")
+            if l != 4:
+                x16 = TO.cast_bf16(x)
+                name = f"down.{l}.downsample.conv"
+                x = conv3d(x16, pack_conv(self.w(name + ".weight")), self.w(name + ".bias"), stride=2, pad=0)
+                self.saved.append(("down", name, x16))
+        x = self._res_fwd(x, "mid.block_1", cin, cin)
+        x = self._attn_fwd(x, "mid.attn_1")
+        x = self._res_fwd(x, "mid.block_2", cin, cin)
+        h, st = groupnorm(x, self.w("norm_out.weight"), self.w("norm_out.bias"), True)
+        z = conv3d(h, pack_conv(self.w("conv_out.weight")), self.w("conv_out.bias"))           # [B, 8, 4, 2, 16]
+        self.saved.append(("out", x, st))
+        # tokeniser: Linear(16 -> 512) + r/a/e embeddings, tokens r-major then a then e
+        r_e, a_e, e_e = self.P["radar_r_emb.weight"].data, self.P["radar_a_emb.weight"].data, self.P["radar_e_emb.weight"].data
+        emb = (r_e[:, None, None, :] + a_e[None, :, None, :] + e_e[None, None, :, :]).reshape(-1, r_e.shape[1])     # [64, 512]
+        tok = (emb + self.P["radar_token_project.bias"].data)[None].repeat(B, 1, 1).contiguous()
+        z2 = z.view(-1, z.shape[-1])
+        _sgemm(z2, self.P["radar_token_project.weight"].data, tok.view(-1, tok.shape[-1]))
+        self.saved.append(("tok", z2, (r_e.shape[0], a_e.shape[0], e_e.shape[0])))
+        return tok
+
+    def backward(self, dtok: torch.Tensor) -> None:
+        """dtok [B, T, 512] f32: gradient w.r.t. the tokens ``forward`` returned.  Accumulates every parameter gradient."""
+        P = self.P
+        _, z2, (nr, na, ne) = self.saved.pop()
+        B = dtok.shape[0]
+        d2 = dtok.reshape(-1, dtok.shape[-1]).contiguous()
+        _sgemm(d2, z2, _g(P["radar_token_project.weight"]), trans_a=True, trans_b=True)          # [512, 16] = dtok^T . z
+        TO.colsum(d2, _g(P["radar_token_project.bias"]))
+        # embedding rows: one-hot selection matrices [B*T, n] (token t = (r*na + a)*ne + e)
+        t = torch.arange(nr * na * ne, device=self.dev)
+        for idx, n, key in ((t // (na * ne), nr, "radar_r_emb.weight"), ((t // ne) % na, na, "radar_a_emb.weight"), (t % ne, ne, "radar_e_emb.weight")):
+            sel = torch.nn.functional.one_hot(idx, n).to(torch.float32).repeat(B, 1).contiguous()
+            _sgemm(sel, d2, _g(P[key]), trans_a=True, trans_b=True)
+        dz = torch.zeros(z2.shape, device=self.dev, dtype=torch.float32)
+        _sgemm(d2, P["radar_token_project.weight"].data, dz, trans_b=True)                       # dtok . Wp
+        _, x, st = self.saved.pop()
+        dz5 = dz.view(*x.shape[:-1], dz.shape[-1])
+        h, _ = groupnorm(x, self.w("norm_out.weight"), self.w("norm_out.bias"), True)
+        conv_wgrad(dz5, h, _g(self.p("conv_out.weight")), _g(self.p("conv_out.bias")))
+        dh = conv_dgrad(dz5, self.w("conv_out.weight"))
+        dx = torch.empty_like(x)
+        groupnorm_bwd(x, st, self.w("norm_out.weight"), self.w("norm_out.bias"), dh, dx, _g(self.p("norm_out.weight")), _g(self.p("norm_out.bias")),
+                      True, False)
+        while self.saved:
+            rec = self.saved.pop()
+            kind = rec[0]
+            if kind == "res":
+                dx = self._res_bwd(rec, dx)
+            elif kind == "attn":
+                dx = self._attn_bwd(rec, dx)
+            elif kind == "down":
+                _, name, x16 = rec
+                conv_wgrad(dx, x16, _g(self.p(name + ".weight")), _g(self.p(name + ".bias")), stride=2, pad=0)
+                dx = down_dgrad(dx, self.w(name + ".weight"))
+            elif kind == "conv_in":
+                cube = rec[1]
+                Bc, R, A, E, cch = cube.shape
+                check(lib().rald_op_conv_in_wgrad(_p(cube), cch, _p(dx), Bc, R, A, E, self.ch, _p(_g(self.p("conv_in.weight"))), _st()))
+                TO.colsum(dx.view(-1, self.ch), _g(self.p("conv_in.bias")))

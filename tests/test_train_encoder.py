@@ -82,3 +82,39 @@ def test_groupnorm_swish_forward_backward_vs_autograd():
         e = (rel_l2(_cf(dx.cpu()) - 1, x.grad), rel_l2(dg.cpu(), g.grad), rel_l2(db.cpu(), b.grad))
         print(f"groupnorm C={Cc} swish={swish}: dx {e[0]:.2e} dgamma {e[1]:.2e} dbeta {e[2]:.2e}")
         assert max(e) < 1e-4
+
+
+def test_encoder_and_tokeniser_forward_backward_vs_oracle_autograd():
+    """EDMPrecond.process_radar_cond (:363-407: Encoder + radar_token_project + r/a/e embeddings) on a full-size cube
+    (128 x 64 x 32 is the smallest the architecture's 64-token attention admits), B = 1: tokens and EVERY parameter
+    gradient against autograd of the CPU oracle (itself pinned to the reference's encoder by G7 / G3)."""
+    from oracle import rald_oracle as O
+    from rald_amd import train_encoder as TE, weights
+    sd = {k: v for k, v in weights.make_state_dict(weights.dit_spec(depth=1), 0).items() if k.startswith("radar_")}
+    cube = synth.radar_cube(1)
+    dtok = synth.normal([1, 64, 512], 630)
+    leaf = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    tok_ref = O.process_radar_cond(leaf, cube)
+    (tok_ref * dtok).sum().backward()
+    params = {k: torch.nn.Parameter(v.clone().cuda()) for k, v in sd.items()}
+    enc = TE.EncoderTrainer(params)
+    tok = enc.forward(cube.cuda())
+    e = rel_l2(tok.cpu(), tok_ref.detach())
+    print("tokens rel_l2", e)
+    assert e < 1.5e-2
+    enc.backward(dtok.cuda())
+    torch.cuda.synchronize()
+    worst = ("", 0.0)
+    for k, p in params.items():
+        assert p.grad is not None, k
+        if k.endswith(".k.bias"):
+            # a bias on the keys shifts every score of a row equally: softmax is invariant, the true gradient is exactly 0
+            # (autograd returns round-off); check that ours is small against the query-bias gradient of the same block
+            qn = float(leaf[k.replace(".k.bias", ".q.bias")].grad.norm())
+            assert float(leaf[k].grad.norm()) < 1e-4 * qn and float(p.grad.norm()) < 3e-2 * qn, k
+            continue
+        e = rel_l2(p.grad.cpu(), leaf[k].grad)
+        if e > worst[1]:
+            worst = (k, e)
+        assert e < 5e-2, (k, e)
+    print("worst encoder parameter-gradient rel_l2:", worst)
