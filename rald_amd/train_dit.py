@@ -285,3 +285,47 @@ class GraphedTrainStep:
         self.opt.step(ema_rate=ema_rate)
         self.g_refresh.replay()
         return self.loss, norm
+
+
+class EdmTrainer:
+    """The reference's training iteration for ``EDMPrecond`` with the radar encoder trained jointly (the shipped
+    ``unfreeze_radar_enc: true``; engine_generation.py:74-110): cube -> radar encoder -> condition tokens -> denoiser ->
+    EDMLoss, backward through all of it, then clip / AdamW / EMA on the flat storage.
+
+        opt = FlatAdamW(model.parameters(), lr=..., ema=True)
+        trainer = EdmTrainer(model, opt)
+        loss, grad_norm = trainer.step(latents, radar_cube, rnd_normal, noise)
+
+    ``rnd_normal`` [B] and ``noise`` [B, N, C] are EDMLoss's two draws (models_radar_generation.py:285, :288); pass
+    ``None`` to draw them here (CPU generator for the log-normal, device generator for the noise)."""
+
+    def __init__(self, model, opt, reducer=None):
+        from .train_encoder import EncoderTrainer
+        named = dict(model.named_parameters())
+        self.model, self.opt, self.reducer = model, opt, reducer
+        depth = 1 + max(int(k.split(".")[2]) for k in named if k.startswith("model.transformer_blocks."))
+        self.dit = DitTrainer({k[len("model."):]: p for k, p in named.items() if k.startswith("model.")}, depth,
+                              sigma_data=float(getattr(model, "sigma_data", 1.0)))
+        self.enc = EncoderTrainer({k: p for k, p in named.items() if k.startswith("radar_")})
+
+    def forward_backward(self, y, cube, rnd_normal, noise):
+        tokens = self.enc.forward(cube[..., 0:1].contiguous() if cube.shape[-1] != 1 else cube)
+        loss, dtok = self.dit.forward_backward(y, tokens, rnd_normal, noise)
+        self.enc.backward(dtok)
+        return loss
+
+    def step(self, y, cube, rnd_normal=None, noise=None, max_norm: float = 10.0, ema_rate: Optional[float] = 0.999):
+        if rnd_normal is None:
+            rnd_normal = torch.randn(y.shape[0])
+        if noise is None:
+            noise = torch.randn(y.shape, device=y.device)
+        self.opt.zero_grad()
+        loss = self.forward_backward(y, cube, rnd_normal, noise)
+        pre = 1.0
+        if self.reducer is not None:
+            self.reducer.start()
+            pre = self.reducer.finish()
+        norm = self.opt.clip_grad_norm_(max_norm, pre_scale=pre)
+        self.opt.step(ema_rate=ema_rate)
+        self.dit.refresh_weights()
+        return loss, norm

@@ -118,3 +118,45 @@ def test_encoder_and_tokeniser_forward_backward_vs_oracle_autograd():
             worst = (k, e)
         assert e < 5e-2, (k, e)
     print("worst encoder parameter-gradient rel_l2:", worst)
+
+
+def test_full_edm_training_step_vs_oracle_autograd_and_loss_decreases():
+    """The reference's training iteration with the radar encoder trained jointly (engine_generation.py:74-110 at the shipped
+    unfreeze_radar_enc = true): cube -> encoder -> tokens -> denoiser (depth 2 here) -> EDMLoss.  Loss and every one of the
+    model's parameter gradients against autograd of the CPU oracle; then three optimizer steps lower the loss."""
+    from oracle import rald_oracle as O
+    from rald_amd import config, models_radar_generation as G, train_dit as TD, weights
+    from rald_amd.train_utils import FlatAdamW
+    depth, Bn = 2, 1
+    sd = weights.make_state_dict(weights.dit_spec(depth=depth), 0)
+    cube, y = synth.radar_cube(Bn), synth.normal([Bn, 512, 32], 640)
+    rnd, noise = synth.normal([Bn, 1, 1], 641), synth.normal([Bn, 512, 32], 642)
+    leaf = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    loss_ref = O.edm_loss(leaf, y, O.process_radar_cond(leaf, cube), rnd, noise, depth)
+    loss_ref.backward()
+    m = G.EDMPrecond(n_latents=512, channels=32, depth=depth, configs=config.shipped_generation_config())
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    opt = FlatAdamW(list(m.parameters()), lr=1e-4, ema=True)
+    tr = TD.EdmTrainer(m, opt)
+    opt.zero_grad()
+    loss = tr.forward_backward(y.cuda(), cube.cuda(), rnd.flatten(), noise.cuda())
+    torch.cuda.synchronize()
+    print("EDM loss (encoder trained jointly) hip / oracle:", float(loss), float(loss_ref.detach()))
+    assert abs(float(loss) - float(loss_ref.detach())) < 5e-3 * float(loss_ref.detach())
+    worst = ("", 0.0)
+    for k, p in m.named_parameters():
+        ref = leaf[k].grad
+        if k.endswith(".k.bias"):
+            continue                                              # exactly-zero gradient: see the encoder test
+        e = rel_l2(p.grad.cpu(), ref)
+        if e > worst[1]:
+            worst = (k, e)
+        assert e < 6e-2, (k, e)
+    print("worst parameter-gradient rel_l2 over the whole model:", worst)
+    losses = [float(loss)]
+    for _ in range(3):
+        l, _ = tr.step(y.cuda(), cube.cuda(), rnd.flatten(), noise.cuda())
+        losses.append(float(l))
+    print("losses:", [round(v, 4) for v in losses])
+    assert losses[-1] < losses[0]
