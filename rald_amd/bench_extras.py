@@ -61,22 +61,17 @@ def _fp8_mode(B=64) -> dict:
 
 
 def _train_step(B=8) -> dict:
-    """one training iteration of the 24-block denoiser under EDMLoss (forward + backward + clip +
-    fused AdamW/EMA + weight refresh), condition tokens given, B = the reference's per-GPU training batch."""
-    from . import train_dit as TD
+    """one training iteration of EDMPrecond as the reference runs it (engine_generation.py:74-110, radar
+    encoder trained jointly): cube -> encoder -> 24-block denoiser -> EDMLoss, backward through all of it, clip +
+    fused AdamW/EMA, weight refresh; B = the reference's per-GPU training batch."""
+    from . import config, models_radar_generation as G, train_dit as TD, weights
     from .train_utils import FlatAdamW
-    m = _denoiser()
-    named = dict(m.named_parameters())
-    opt = FlatAdamW(list(named.values()), lr=1e-4, ema=True)
-    tr = TD.DitTrainer(named, 24)
-    y, cond = synth.normal([B, 512, 32], 1).cuda(), synth.cond_tokens(B).cuda()
+    m = G.EDMPrecond(n_latents=512, channels=32, depth=24, configs=config.shipped_generation_config())
+    m.load_state_dict(weights.make_state_dict(weights.dit_spec(depth=24), 0), strict=True)
+    m = m.cuda()
+    opt = FlatAdamW(list(m.parameters()), lr=1e-4, ema=True)
+    tr = TD.EdmTrainer(m, opt)
+    y, cube = synth.normal([B, 512, 32], 1).cuda(), synth.radar_cube(B).cuda()
     rnd, noise = synth.normal([B], 2), synth.normal([B, 512, 32], 3).cuda()
-
-    def step():
-        opt.zero_grad()
-        tr.forward_backward(y, cond, rnd, noise)
-        opt.clip_grad_norm_(10.0)
-        opt.step(ema_rate=0.999)
-        tr.refresh_weights()
-    dt = _time(step, reps=4, warm=2)
+    dt = _time(lambda: tr.step(y, cube, rnd, noise), reps=3, warm=2)
     return {"train_step_ms_B8": dt * 1e3, "train_samples_per_s_B8": B / dt}

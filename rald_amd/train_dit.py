@@ -11,9 +11,9 @@ runs forward + backward of ``LatentArrayTransformer`` with the kernels of ``trai
 ``block_forward`` / ``block_backward``, plus the timestep-embedding MLP, the AdaLN linears, proj_in / norm /
 proj_out and the loss) and writes every gradient into the parameters' ``.grad`` views of the flat buffer.
 
-Scope: the transformer and the loss, with the radar condition TOKENS as an input (their gradient is
-returned).  The radar encoder's backward (the shipped config trains it jointly, ``unfreeze_radar_enc``) is
-not built, so this is not yet the reference's full training step.
+``DitTrainer`` covers the transformer and the loss with the radar condition TOKENS as an input (their gradient
+is returned); ``EdmTrainer`` adds the radar encoder + tokeniser (``train_encoder.EncoderTrainer``), which the
+shipped config trains jointly (``unfreeze_radar_enc``), and the optimizer step: the reference's whole iteration.
 """
 from __future__ import annotations
 

@@ -11,9 +11,8 @@ softmax backward element-wise; the key-side gradients use the transposed orienta
 dP^T = V.dO^T, with the query's log-sum-exp and delta broadcast along columns), which costs two more thin
 GEMMs instead of transposing the [heads, N, N] probability tensors.
 
-Status: one block forward+backward, gradient parity against autograd of the CPU oracle
-(tests/test_train_block.py).  The loop over 24 blocks, the timestep-embedding / AdaLN-linear / proj_in /
-proj_out gradients and the radar-encoder backward are not built yet.
+Gradient parity against autograd of the CPU oracle: tests/test_train_block.py (one block, whole denoiser);
+the loop over blocks, embeddings and loss live in train_dit.py, the radar encoder in train_encoder.py.
 """
 from __future__ import annotations
 
