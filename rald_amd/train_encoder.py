@@ -100,7 +100,7 @@ def conv_wgrad(dy: torch.Tensor, x16: torch.Tensor, dW: torch.Tensor, dbias: Opt
     M = dy.numel() // Cout
     dy2 = dy.reshape(M, Cout)
     dW2 = dW.view(Cout, Cin * 27)
-    nchunk = max(64, min(M, ((1 << 27) // (Cin * 27 * 2)) // 64 * 64))
+    nchunk = max(64, min(M, 1 << max(6, ((1 << 27) // (Cin * 27 * 2)).bit_length() - 1)))      # power of two, <= 128 MiB of patches
     for m0 in range(0, M, nchunk):
         n = min(nchunk, M - m0)
         npad = -(-n // 64) * 64                              # the GEMM contracts over the chunk: multiple of 64 (zero rows beyond M)
@@ -109,7 +109,17 @@ def conv_wgrad(dy: torch.Tensor, x16: torch.Tensor, dW: torch.Tensor, dbias: Opt
         rows = dy2[m0:m0 + n]
         if npad != n:
             rows = torch.cat([rows, torch.zeros(npad - n, Cout, device=dy.device, dtype=dy.dtype)], 0)
-        op_gemm_nt(TO.T2(rows), col, epilogue=2, C_inout=dW2)
+        dyT = TO.T2(rows)                                    # [Cout, npad]
+        ks = 1
+        while ks < 16 and npad % (2 * ks * 2048) == 0:       # split the long contraction: Cout x Cin*27 outputs alone are too few tiles
+            ks *= 2
+        if ks == 1:
+            op_gemm_nt(dyT, col, epilogue=2, C_inout=dW2)
+        else:
+            kk = npad // ks
+            part = torch.empty(ks, Cout, Cin * 27, device=dy.device, dtype=torch.float32)
+            TO.gemm2(dyT, npad, kk, 0, col, npad, kk, 0, part, Cin * 27, Cout * Cin * 27, 0, Cout, Cin * 27, kk, ks, 1, epilogue=1)
+            TO.colsum(part.view(ks, Cout * Cin * 27), dW2.view(-1))
     if dbias is not None:
         TO.colsum(dy2, dbias)
 
