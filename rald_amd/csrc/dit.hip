@@ -123,10 +123,8 @@ int Dit::create() {
             auto U8 = [&](size_t n) { return (unsigned char*)arena.alloc(n, true); };
             l.q8_qk = U8((size_t)2 * D * D); l.s8_qk = U8((size_t)2 * D * D / 32);
             l.q8_v = U8((size_t)D * D);      l.s8_v = U8((size_t)D * D / 32);
-            l.q8_o = U8((size_t)D * D);      l.s8_o = U8((size_t)D * D / 32);
             l.q8_q2 = U8((size_t)D * D);     l.s8_q2 = U8((size_t)D * D / 32);
-            l.q8_o2 = U8((size_t)D * D);     l.s8_o2 = U8((size_t)D * D / 32);
-            RALD_CHECK(l.q8_qk && l.s8_qk && l.q8_v && l.s8_v && l.q8_o && l.s8_o && l.q8_q2 && l.s8_q2 && l.q8_o2 && l.s8_o2,
+            RALD_CHECK(l.q8_qk && l.s8_qk && l.q8_v && l.s8_v && l.q8_q2 && l.s8_q2,
                        "dit: device allocation failed");
         }
     }
@@ -240,9 +238,7 @@ int Dit::finalize() {
         for (auto& l : layers) {
             RALD_TRY(quantize_mx8(l.w_qk, 1, D, l.q8_qk, D, l.s8_qk, 2 * D, D, nullptr));
             RALD_TRY(quantize_mx8(l.w_v, 1, D, l.q8_v, D, l.s8_v, D, D, nullptr));
-            RALD_TRY(quantize_mx8(l.w_o, 1, D, l.q8_o, D, l.s8_o, D, D, nullptr));
             RALD_TRY(quantize_mx8(l.w_q2, 1, D, l.q8_q2, D, l.s8_q2, D, D, nullptr));
-            RALD_TRY(quantize_mx8(l.w_o2, 1, D, l.q8_o2, D, l.s8_o2, D, D, nullptr));
         }
         RALD_HIP(hipDeviceSynchronize());
     }
@@ -253,7 +249,7 @@ int Dit::finalize() {
 int Dit::reserve(int B) {
     if (B <= ws_batch) return 0;
     RALD_HIP(hipDeviceSynchronize());
-    for (void* p : {(void*)ws_h8, (void*)ws_hs, (void*)ws_o8, (void*)ws_os})
+    for (void* p : {(void*)ws_h8, (void*)ws_hs})
         if (p) arena.release(p);
     for (void* p : {(void*)ws_x, (void*)ws_h, (void*)ws_qk, (void*)ws_vt, (void*)ws_o, (void*)ws_q2, (void*)ws_g, (void*)ws_tok,
                     (void*)ws_xcur, (void*)ws_xeul, (void*)ws_den, (void*)ws_dcur})
@@ -277,9 +273,7 @@ int Dit::reserve(int B) {
     if (cfg.qkv_dtype == 1) {
         ws_h8 = (unsigned char*)arena.alloc(M * D, true);
         ws_hs = (unsigned char*)arena.alloc(M * D / 32, true);
-        ws_o8 = (unsigned char*)arena.alloc(M * D, true);
-        ws_os = (unsigned char*)arena.alloc(M * D / 32, true);
-        RALD_CHECK(ws_h8 && ws_hs && ws_o8 && ws_os, "dit: workspace allocation failed");
+        RALD_CHECK(ws_h8 && ws_hs, "dit: workspace allocation failed");
     }
     ws_batch = B;
     return 0;
@@ -408,11 +402,11 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
     };
     RALD_TRY(proj_in(x, w_in, ws_x, M, C, D, coef, cstride, NL, st));
     if (cfg.qkv_dtype == 1) {
-        // ---- MXFP8 attention projections (BASELINE config #5).  The AdaLN outputs that feed q/k/v (norm1,
-        // norm2) and the attention outputs that feed to_out are quantised to e4m3 + e8m0/32 and multiplied on
-        // v_mfma_scale_f32_16x16x128_f8f6f4; the feed-forward stays bf16.  First version: the quantisers are
-        // separate passes (LayerNorm -> MXFP8 in one kernel, attention output in its own), not yet fused into
-        // the producing GEMM / attention epilogues.
+        // ---- MXFP8 q/k/v projections (BASELINE config #5).  The AdaLN outputs that feed to_q / to_k / to_v (norm1,
+        // norm2) are produced directly in e4m3 + e8m0/32 by the fused residual+LayerNorm GEMM epilogue (or by
+        // layernorm_mod_mx8 where that kernel does not pay) and multiplied on v_mfma_scale_f32_16x16x128_f8f6f4;
+        // to_out and the feed-forward stay bf16 (their A operands - attention output, GEGLU output - would need
+        // quantising epilogues of their own before fp8 pays there).
         auto ln8 = [&](const float* m) { return layernorm_mod_mx8(ws_x, ws_h8, ws_hs, M, D, m, m + D, gstride, NL, 1.0f, 1e-5f, st); };
         auto mx = [&](const unsigned char* A8, const unsigned char* SA, const unsigned char* B8, const unsigned char* SB, void* Cp, int64_t ldc,
                       const float* bias, int m, int n) {
@@ -421,9 +415,18 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
             a.g = gemm_args(nullptr, D, nullptr, D, Cp, ldc, bias, m, n, D);
             return a;
         };
-        auto out_proj8 = [&](const unsigned char* W8, const unsigned char* S8, const float* bias) -> int {
-            RALD_TRY(quantize_mx8(ws_o, 1, D, ws_o8, D, ws_os, M, D, st));
-            return gemm_mx8(mx(ws_o8, ws_os, W8, S8, ws_x, D, bias, M, D), EPI_RESID, st);
+        // x += A.W^T + bias (bf16 GEMM), then the next AdaLN as MXFP8 into ws_h8 / ws_hs
+        auto resid_ln8 = [&](const bf16* A, int64_t lda, const bf16* W, int64_t ldw, const float* bias, int K, const float* mnext) -> int {
+            if (fuse_ln && gemm_resid_ln_pays(M, K)) {
+                GemmLnArgs g;
+                g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.x = ws_x; g.h = nullptr; g.h8 = ws_h8; g.hs = ws_hs;
+                g.g = mnext; g.b = mnext + D; g.gstride = gstride; g.rows_per_group = NL; g.add_one = 1.0f; g.eps = 1e-5f;
+                g.M = M; g.K = K;
+                return gemm_resid_ln(g, st);
+            }
+            GemmArgs o = gemm_args(A, lda, W, ldw, ws_x, D, bias, M, D, K);
+            RALD_TRY(gemm_nt(o, EPI_RESID, st));
+            return ln8(mnext);
         };
         RALD_TRY(ln8(mod));                                                               // norm1 of block 0
         for (int li = 0; li < L; ++li) {
@@ -443,8 +446,7 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
             a1.O = ws_o; a1.ldo = D; a1.strideO = (int64_t)NL * D;
             a1.nq = NL; a1.nk = NL; a1.k_rows = NL; a1.heads = cfg.n_heads; a1.batch = B; a1.scale = scale; a1.q_prescaled = 1;
             RALD_TRY(attention_d64(a1, st));
-            RALD_TRY(out_proj8(l.q8_o, l.s8_o, l.b_o));
-            RALD_TRY(ln8(m2));
+            RALD_TRY(resid_ln8(ws_o, D, l.w_o, D, l.b_o, D, m2));                        // + norm2 (MXFP8) for to_q of attn2
             Mx8Args q2 = mx(ws_h8, ws_hs, l.q8_q2, l.s8_q2, ws_q2, D, nullptr, M, D);
             q2.g.alpha = qscale;
             RALD_TRY(gemm_mx8(q2, EPI_BF16, st));
@@ -455,13 +457,11 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
             a2.O = ws_o; a2.ldo = D; a2.strideO = (int64_t)NL * D;
             a2.nq = NL; a2.nk = T; a2.k_rows = T; a2.heads = cfg.n_heads; a2.batch = B; a2.scale = scale; a2.q_prescaled = 1;
             RALD_TRY(attention_d64(a2, st));
-            RALD_TRY(out_proj8(l.q8_o2, l.s8_o2, l.b_o2));
-            RALD_TRY(layernorm_mod(ws_x, ws_h, M, D, m3, m3 + D, gstride, NL, 1.0f, 1e-5f, st));     // norm3 feeds the bf16 feed-forward
+            RALD_TRY(resid_ln(ws_o, D, l.w_o2, D, l.b_o2, D, m3));                       // + norm3 (bf16) for the feed-forward
             GemmArgs f1 = gemm_args(ws_h, D, l.w_ff1, D, ws_g, 4 * D, l.b_ff1, M, 8 * D, D);
             RALD_TRY(gemm_nt(f1, EPI_GEGLU, st));
-            GemmArgs f2 = gemm_args(ws_g, 4 * D, l.w_ff2, 4 * D, ws_x, D, l.b_ff2, M, D, 4 * D);
-            RALD_TRY(gemm_nt(f2, EPI_RESID, st));
-            if (li + 1 < L) RALD_TRY(ln8(mod + (int64_t)((li + 1) * 3) * 2 * D));        // norm1 of the next block
+            if (li + 1 < L) RALD_TRY(resid_ln8(ws_g, 4 * D, l.w_ff2, 4 * D, l.b_ff2, 4 * D, mod + (int64_t)((li + 1) * 3) * 2 * D));
+            else RALD_TRY(resid_ln(ws_g, 4 * D, l.w_ff2, 4 * D, l.b_ff2, 4 * D, nullptr));
         }
         RALD_TRY(final_norm_proj(ws_x, norm_g, norm_b, w_out, x, out, M, D, C, coef, cstride, NL, st));
         return 0;

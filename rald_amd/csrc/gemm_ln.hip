@@ -16,6 +16,7 @@
 //   3. x_new and h leave through the wave-private LDS transpose as whole rows (16 B per lane).
 #include "common.h"
 #include "kernels.h"
+#include "mx8.h"
 
 namespace rald {
 
@@ -189,7 +190,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs 
                 const int r = r0 + lane / LPR, pc = lane % LPR;
                 const int mm = mb + i * 16 + r;
                 const uint4 v = *reinterpret_cast<const uint4*>(patch + r * STRIDE_H + pc * 16);
-                if (mm < a.M) *reinterpret_cast<uint4*>(a.h + (int64_t)mm * BN + nb + pc * 8) = v;
+                if (a.h8) {
+                    // MXFP8 output: this lane's 16-byte piece is 8 consecutive columns, 4 consecutive lanes = one 32-column
+                    // block (nb and the pieces are 32-column aligned); every lane of the wave takes part in the shuffles
+                    const bf16x8 hv = *reinterpret_cast<const bf16x8*>(&v);
+                    float f[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = (float)hv[e];
+                    const int64_t mc = mm < a.M ? mm : a.M - 1;
+                    const int col = nb + pc * 8;
+                    unsigned char q8[8] __attribute__((aligned(8)));
+                    unsigned char sc;
+                    mx8_block(f, q8, &sc, true);
+                    if (mm < a.M) {
+                        *reinterpret_cast<uint2*>(a.h8 + mc * BN + col) = *reinterpret_cast<const uint2*>(q8);
+                        if ((pc & 3) == 0) a.hs[mc * (BN / 32) + col / 32] = sc;
+                    }
+                } else if (mm < a.M) *reinterpret_cast<uint4*>(a.h + (int64_t)mm * BN + nb + pc * 8) = v;
             }
         }
     }
@@ -212,7 +229,7 @@ static int launch_ln(const GemmLnArgs& a, hipStream_t st) {
 int gemm_resid_ln(const GemmLnArgs& a, hipStream_t st) {
     RALD_CHECK(a.M > 0 && a.K > 0 && a.K % 64 == 0, "gemm_resid_ln: bad shape");
     RALD_CHECK(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.lda >= a.K && a.ldw >= a.K, "gemm_resid_ln: leading dimensions");
-    RALD_CHECK(a.A && a.W && a.bias && a.x && a.h && a.g && a.b && a.rows_per_group > 0, "gemm_resid_ln: null argument");
+    RALD_CHECK(a.A && a.W && a.bias && a.x && (a.h || (a.h8 && a.hs)) && a.g && a.b && a.rows_per_group > 0, "gemm_resid_ln: null argument");
     RALD_CHECK(((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.W % 16 == 0) && ((uintptr_t)a.x % 16 == 0) && ((uintptr_t)a.h % 16 == 0) &&
                ((uintptr_t)a.g % 16 == 0) && ((uintptr_t)a.b % 16 == 0) && a.gstride % 4 == 0, "gemm_resid_ln: 16-byte alignment");
     // 128-row tiles (all 160 KiB of LDS) when they cover the chip, 64-row tiles for smaller M

@@ -44,7 +44,9 @@ struct GemmLnArgs {
     const bf16* W; int64_t ldw;
     const float* bias;
     float* x;                 // [M][512] fp32, updated in place
-    bf16* h;                  // [M][512] bf16 out
+    bf16* h;                  // [M][512] bf16 out (skipped when h8 is set)
+    unsigned char* h8 = nullptr;   // optional MXFP8 form of h instead: e4m3 [M][512] ...
+    unsigned char* hs = nullptr;   // ... + e8m0 scales [M][16]
     const float* g; const float* b; int64_t gstride; int rows_per_group; float add_one, eps;
     int M, K;
 };

@@ -93,7 +93,7 @@ class LatentArrayTransformer(_HipBacked):
         self.context_dim = context_dim
         self.depth, self.n_heads, self.d_head = depth, n_heads, d_head
         object.__setattr__(self, "_owner", _owner)      # EDMPrecond that shares its handle (not a submodule)
-        self.qkv_dtype = os.environ.get("RALD_QKV_DTYPE", "bf16")   # "bf16" | "fp8" (MXFP8 q/k/v/out projections, BASELINE config #5)
+        self.qkv_dtype = os.environ.get("RALD_QKV_DTYPE", "bf16")   # "bf16" | "fp8" (MXFP8 q/k/v projections, BASELINE config #5)
         self._hip = None
         self._hip_fp = None
         spec = _w.dit_spec(channels=in_channels, depth=depth, n_heads=n_heads, d_head=d_head, t_channels=t_channels,

@@ -106,11 +106,11 @@ def test_hip_gemm_mx8_rejects_bad_shapes():
 
 @pytest.mark.gpu
 def test_fp8_qkv_mode_vs_reference_goldens():
-    """BASELINE config #5: the denoiser with MXFP8 attention projections (qkv_dtype='fp8') against the SAME
+    """BASELINE config #5: the denoiser with MXFP8 q/k/v projections (qkv_dtype='fp8') against the SAME
     fp32 goldens as the bf16 mode (SURVEY.md §8d 'fp8: same three numbers').  Stated tolerances for this mode:
-    one NFE D_x rel-L2 <= 1e-1 (measured 6.9e-2 / 6.0e-2 / 1.4e-4 at sigma 80 / 1 / 0.002), 18-step sampler
-    <= 1e-1 (measured 4.6e-2), raw F_x within 1.5e-1 of the bf16 mode (measured 8.8e-2 on these random
-    weights).  e4m3 keeps 3 mantissa bits: ~3.8 % per projection (test_hip_gemm_mx8_*), 120 projections per NFE."""
+    one NFE D_x rel-L2 <= 1e-1 (measured 3.5e-2 / 3.0e-2 / 7e-5 at sigma 80 / 1 / 0.002), 18-step sampler
+    <= 1e-1 (measured 2.9e-2), raw F_x within 1.5e-1 of the bf16 mode (measured 6.5e-2 on these random
+    weights).  e4m3 keeps 3 mantissa bits: ~3.8 % per projection (test_hip_gemm_mx8_*), 72 fp8 projections per NFE."""
     from conftest import load_golden, rel_l2
     from rald_amd import config, models_radar_generation as G, weights
     m = G.LatentArrayTransformer(in_channels=32, t_channels=256, n_heads=8, d_head=64, depth=24)
