@@ -49,15 +49,22 @@ def _denoiser(depth=24):
 
 
 def _fp8_mode(B=64) -> dict:
-    """BASELINE config #5: one NFE with MXFP8 attention projections (qkv_dtype='fp8'), same batch as the headline."""
-    m = _denoiser()
-    m.qkv_dtype = "fp8"
-    h = m._handle(512, 64)
-    h.set_sigmas([1.0])
+    """BASELINE config #5: one NFE with MXFP8 q/k/v projections (qkv_dtype='fp8') and with the GEGLU projection in MXFP8
+    as well ('fp8_ff1'), same batch as the headline (which stays bf16)."""
+    out = {}
     x = synth.latents(range(B)).cuda()
-    cache = h.encode_cond_tokens(synth.cond_tokens(B).cuda())
-    dt = _time(lambda: h.denoise(x, cache, 0), reps=10, warm=3)
-    return {"fp8_qkv_nfe_ms_B64": dt * 1e3, "fp8_qkv_sample_nfe_per_s": B / dt}
+    cond = synth.cond_tokens(B).cuda()
+    for mode, key in (("fp8", "fp8_qkv"), ("fp8_ff1", "fp8_qkv_ff1")):
+        m = _denoiser()
+        m.qkv_dtype = mode
+        h = m._handle(512, 64)
+        h.set_sigmas([1.0])
+        cache = h.encode_cond_tokens(cond)
+        dt = _time(lambda: h.denoise(x, cache, 0), reps=10, warm=3)
+        out[f"{key}_nfe_ms_B64"] = dt * 1e3
+        out[f"{key}_sample_nfe_per_s"] = B / dt
+        del m, h
+    return out
 
 
 def _train_step(B=8) -> dict:

@@ -95,7 +95,7 @@ int Dit::create() {
     const auto& c = cfg;
     D = c.n_heads * c.d_head;
     RALD_CHECK(c.d_head == 64, "dit: only d_head = 64 is implemented");
-    RALD_CHECK(c.qkv_dtype == 0 || c.qkv_dtype == 1, "dit: qkv_dtype must be 0 (bf16) or 1 (MXFP8)");
+    RALD_CHECK(c.qkv_dtype >= 0 && c.qkv_dtype <= 2, "dit: qkv_dtype must be 0 (bf16), 1 (MXFP8 q/k/v) or 2 (MXFP8 q/k/v + GEGLU projection)");
     RALD_CHECK(D == 512, "dit: inner dim (n_heads*d_head) must be 512");
     RALD_CHECK(c.n_latents > 0 && c.n_latents % 64 == 0, "dit: n_latents must be a positive multiple of 64");
     RALD_CHECK(c.channels >= 1 && c.channels <= 64, "dit: channels must be in [1,64]");
@@ -119,11 +119,12 @@ int Dit::create() {
         l.b_ff1 = F32((size_t)8 * D);
         l.w_ff2 = B16((size_t)D * 4 * D);
         l.b_ff2 = F32(D);
-        if (c.qkv_dtype == 1) {
+        if (c.qkv_dtype >= 1) {
             auto U8 = [&](size_t n) { return (unsigned char*)arena.alloc(n, true); };
             l.q8_qk = U8((size_t)2 * D * D); l.s8_qk = U8((size_t)2 * D * D / 32);
             l.q8_v = U8((size_t)D * D);      l.s8_v = U8((size_t)D * D / 32);
             l.q8_q2 = U8((size_t)D * D);     l.s8_q2 = U8((size_t)D * D / 32);
+            if (c.qkv_dtype == 2) { l.q8_ff1 = U8((size_t)8 * D * D); l.s8_ff1 = U8((size_t)8 * D * D / 32); RALD_CHECK(l.q8_ff1 && l.s8_ff1, "dit: device allocation failed"); }
             RALD_CHECK(l.q8_qk && l.s8_qk && l.q8_v && l.s8_v && l.q8_q2 && l.s8_q2,
                        "dit: device allocation failed");
         }
@@ -234,11 +235,12 @@ int Dit::load_weight(const std::string& name, const float* data, int64_t nelem) 
 
 int Dit::finalize() {
     for (const auto& k : expected) RALD_CHECK(loaded.count(k), "dit: missing key '" + k + "' (strict load)");
-    if (cfg.qkv_dtype == 1) {                  // MXFP8 copies of the attention projections, from the bf16 weights
+    if (cfg.qkv_dtype >= 1) {                  // MXFP8 copies of the attention projections, from the bf16 weights
         for (auto& l : layers) {
             RALD_TRY(quantize_mx8(l.w_qk, 1, D, l.q8_qk, D, l.s8_qk, 2 * D, D, nullptr));
             RALD_TRY(quantize_mx8(l.w_v, 1, D, l.q8_v, D, l.s8_v, D, D, nullptr));
             RALD_TRY(quantize_mx8(l.w_q2, 1, D, l.q8_q2, D, l.s8_q2, D, D, nullptr));
+            if (cfg.qkv_dtype == 2) RALD_TRY(quantize_mx8(l.w_ff1, 1, D, l.q8_ff1, D, l.s8_ff1, 8 * D, D, nullptr));
         }
         RALD_HIP(hipDeviceSynchronize());
     }
@@ -270,7 +272,7 @@ int Dit::reserve(int B) {
     ws_dcur = (float*)arena.alloc(nl * 4, true);
     RALD_CHECK(ws_x && ws_h && ws_qk && ws_vt && ws_o && ws_q2 && ws_g && ws_tok && ws_xcur && ws_xeul && ws_den && ws_dcur,
                "dit: workspace allocation failed");
-    if (cfg.qkv_dtype == 1) {
+    if (cfg.qkv_dtype >= 1) {
         ws_h8 = (unsigned char*)arena.alloc(M * D, true);
         ws_hs = (unsigned char*)arena.alloc(M * D / 32, true);
         RALD_CHECK(ws_h8 && ws_hs, "dit: workspace allocation failed");
@@ -401,8 +403,8 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
         return 0;
     };
     RALD_TRY(proj_in(x, w_in, ws_x, M, C, D, coef, cstride, NL, st));
-    if (cfg.qkv_dtype == 1) {
-        // ---- MXFP8 q/k/v projections (BASELINE config #5).  The AdaLN outputs that feed to_q / to_k / to_v (norm1,
+    if (cfg.qkv_dtype >= 1) {
+        // ---- MXFP8 q/k/v projections (BASELINE config #5; qkv_dtype 2 adds the GEGLU projection of the feed-forward).  The AdaLN outputs that feed to_q / to_k / to_v (norm1,
         // norm2) are produced directly in e4m3 + e8m0/32 by the fused residual+LayerNorm GEMM epilogue (or by
         // layernorm_mod_mx8 where that kernel does not pay) and multiplied on v_mfma_scale_f32_16x16x128_f8f6f4;
         // to_out and the feed-forward stay bf16 (their A operands - attention output, GEGLU output - would need
@@ -457,9 +459,15 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
             a2.O = ws_o; a2.ldo = D; a2.strideO = (int64_t)NL * D;
             a2.nq = NL; a2.nk = T; a2.k_rows = T; a2.heads = cfg.n_heads; a2.batch = B; a2.scale = scale; a2.q_prescaled = 1;
             RALD_TRY(attention_d64(a2, st));
-            RALD_TRY(resid_ln(ws_o, D, l.w_o2, D, l.b_o2, D, m3));                       // + norm3 (bf16) for the feed-forward
-            GemmArgs f1 = gemm_args(ws_h, D, l.w_ff1, D, ws_g, 4 * D, l.b_ff1, M, 8 * D, D);
-            RALD_TRY(gemm_nt(f1, EPI_GEGLU, st));
+            if (cfg.qkv_dtype == 2) {
+                RALD_TRY(resid_ln8(ws_o, D, l.w_o2, D, l.b_o2, D, m3));                  // + norm3 (MXFP8)
+                Mx8Args f1 = mx(ws_h8, ws_hs, l.q8_ff1, l.s8_ff1, ws_g, 4 * D, l.b_ff1, M, 8 * D);
+                RALD_TRY(gemm_mx8(f1, EPI_GEGLU, st));
+            } else {
+                RALD_TRY(resid_ln(ws_o, D, l.w_o2, D, l.b_o2, D, m3));                   // + norm3 (bf16) for the feed-forward
+                GemmArgs f1 = gemm_args(ws_h, D, l.w_ff1, D, ws_g, 4 * D, l.b_ff1, M, 8 * D, D);
+                RALD_TRY(gemm_nt(f1, EPI_GEGLU, st));
+            }
             if (li + 1 < L) RALD_TRY(resid_ln8(ws_g, 4 * D, l.w_ff2, 4 * D, l.b_ff2, 4 * D, mod + (int64_t)((li + 1) * 3) * 2 * D));
             else RALD_TRY(resid_ln(ws_g, 4 * D, l.w_ff2, 4 * D, l.b_ff2, 4 * D, nullptr));
         }

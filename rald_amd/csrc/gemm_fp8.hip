@@ -183,7 +183,8 @@ static int launch_mx8(const Mx8Args& a, int epi, hipStream_t st) {
         case EPI_BF16:  return launch_mx8_epi<BM, BN, WM, WN, EPI_BF16>(a, st);
         case EPI_F32:   return launch_mx8_epi<BM, BN, WM, WN, EPI_F32>(a, st);
         case EPI_RESID: return launch_mx8_epi<BM, BN, WM, WN, EPI_RESID>(a, st);
-        default: set_error("gemm_mx8: epilogue must be bf16, f32 or resid"); return 1;
+        case EPI_GEGLU: return launch_mx8_epi<BM, BN, WM, WN, EPI_GEGLU>(a, st);
+        default: set_error("gemm_mx8: bad epilogue"); return 1;
     }
 }
 
@@ -197,7 +198,8 @@ int gemm_mx8(const Mx8Args& a0, int epi, hipStream_t st) {
     RALD_CHECK(g.lda % 16 == 0 && g.ldb % 16 == 0 && g.lda >= g.K && g.ldb >= g.K, "gemm_mx8: lda/ldb must be >= K and multiples of 16 bytes");
     RALD_CHECK(a.A8 && a.B8 && a.SA && a.SB && g.C, "gemm_mx8: null operand");
     RALD_CHECK(((uintptr_t)a.A8 % 16 == 0) && ((uintptr_t)a.B8 % 16 == 0) && ((uintptr_t)g.C % 16 == 0), "gemm_mx8: pointers must be 16-byte aligned");
-    RALD_CHECK(g.ldc % 4 == 0 && g.ldc >= g.N, "gemm_mx8: ldc must be >= N and a multiple of 4");
+    if (epi == EPI_GEGLU) RALD_CHECK(g.N % 128 == 0 && g.bias != nullptr && g.ldc % 4 == 0 && g.ldc >= g.N / 2, "gemm_mx8: GEGLU needs N % 128 == 0, a packed bias and ldc >= N/2");
+    else RALD_CHECK(g.ldc % 4 == 0 && g.ldc >= g.N, "gemm_mx8: ldc must be >= N and a multiple of 4");
     RALD_CHECK((int64_t)g.M * (g.K / 32) < ((int64_t)1 << 31) && (int64_t)g.N * (g.K / 32) < ((int64_t)1 << 31), "gemm_mx8: scale index overflow");
     a.g.ablate = 64;                           // streamed (non-temporal) bf16 output, as in gemm_nt
     const int64_t wg256 = (int64_t)(g.M / 256) * (g.N / 256) * g.batch;

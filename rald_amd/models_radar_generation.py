@@ -75,9 +75,10 @@ class _HipBacked(nn.Module):
 # LatentArrayTransformer (:171-233)
 # ----------------------------------------------------------------------------------------------
 def _qkv_code(name: str) -> int:
-    if name not in ("bf16", "fp8"):
-        raise ValueError("qkv_dtype must be 'bf16' or 'fp8'")
-    return 1 if name == "fp8" else 0
+    codes = {"bf16": 0, "fp8": 1, "fp8_ff1": 2}
+    if name not in codes:
+        raise ValueError("qkv_dtype must be 'bf16', 'fp8' (MXFP8 q/k/v) or 'fp8_ff1' (MXFP8 q/k/v + GEGLU projection)")
+    return codes[name]
 
 
 class LatentArrayTransformer(_HipBacked):

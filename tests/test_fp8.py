@@ -139,3 +139,24 @@ def test_fp8_qkv_mode_vs_reference_goldens():
     with pytest.raises(ValueError):
         m.qkv_dtype = "int4"
         m(x, t, cond=cond)
+
+
+@pytest.mark.gpu
+def test_fp8_ff1_mode_vs_reference_goldens():
+    """qkv_dtype='fp8_ff1': MXFP8 q/k/v AND the GEGLU projection (its input, the norm3 output, also comes straight from the
+    fused LayerNorm epilogue).  Same goldens; stated tolerances: one NFE <= 1e-1, 18-step sampler <= 1e-1."""
+    from conftest import load_golden, rel_l2
+    from rald_amd import config, models_radar_generation as G, weights
+    edm = G.EDMPrecond(n_latents=512, channels=32, depth=24, configs=config.shipped_generation_config())
+    edm.load_state_dict(weights.make_state_dict(weights.dit_spec(depth=24), 0), strict=True)
+    edm = edm.cuda()
+    edm.qkv_dtype = "fp8_ff1"
+    g3, g4 = load_golden("g3_precond.npz"), load_golden("g4_sample18.npz")
+    cube, x = synth.radar_cube(2).cuda(), synth.latents([0, 1]).cuda()
+    for s in (80.0, 1.0, 0.002):
+        err = rel_l2(edm(x * max(s, 1.0), torch.tensor(s), cube, "radar"), g3[f"d_sigma_{s}"])
+        print(f"fp8_ff1 mode, sigma {s}: D_x rel_l2 {err}")
+        assert err < 1e-1
+    err = rel_l2(edm.sample(cond=cube, batch_seeds=None, cond_type="radar"), g4["sample"])
+    print("fp8_ff1 mode, 18-step sampler rel_l2", err)
+    assert err < 1e-1
