@@ -14,6 +14,8 @@
 //   2. per-row sum / sum-of-squares: 32 in-lane values, 2 cross-lane steps, then across the WN waves
 //      through a 4 KiB LDS table and ONE workgroup barrier (single-pass variance in fp32: 512 terms);
 //   3. x_new and h leave through the wave-private LDS transpose as whole rows (16 B per lane).
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 #include "mx8.h"
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs 
         }
     }
 
+    const bool nt_io = a.nt_io != 0;
     // ---- 1. v = acc + bias + x_old (accumulator layout), row partial sums -------------------------
     const int mb = m0 + wm * (BM / WM);
     const int nb = wn * (BN / WN);
@@ -117,7 +120,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs 
         for (int j = 0; j < NT; ++j) {
             const int n = nb + j * 16 + 4 * fq;
             const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
-            const float4 xo = *reinterpret_cast<const float4*>(a.x + (int64_t)m * BN + n);
+            // the residual stream, the new x and h are touched once per call: non-temporal, so they do not push the
+            // weight panel (the only re-read operand) out of L2
+            typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+            const nt_f32x4 xv = nt_io ? __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(a.x + (int64_t)m * BN + n))
+                                      : *reinterpret_cast<const nt_f32x4*>(a.x + (int64_t)m * BN + n);
+            const float4 xo = make_float4(xv[0], xv[1], xv[2], xv[3]);
             f32x4 v = acc[i][j];
             v[0] += b.x + xo.x; v[1] += b.y + xo.y; v[2] += b.z + xo.z; v[3] += b.w + xo.w;
             acc[i][j] = v;
@@ -166,7 +174,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs 
                 const int r = r0 + lane / LPR, pc = lane % LPR;
                 const int m = mb + i * 16 + r;
                 const uint4 v = *reinterpret_cast<const uint4*>(patch + r * STRIDE_F + pc * 16);
-                if (m < a.M) *reinterpret_cast<uint4*>(a.x + (int64_t)m * BN + nb + pc * 4) = v;
+                if (m < a.M) {
+                    typedef unsigned int nt_u32x4 __attribute__((ext_vector_type(4)));
+                    if (nt_io) __builtin_nontemporal_store(nt_u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_u32x4*>(a.x + (int64_t)m * BN + nb + pc * 4));
+                    else *reinterpret_cast<uint4*>(a.x + (int64_t)m * BN + nb + pc * 4) = v;
+                }
             }
         }
         // h = (v - mean) * rstd * (add_one + g) + b ; modulation row of this row's sample
@@ -206,7 +218,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs 
                         *reinterpret_cast<uint2*>(a.h8 + mc * BN + col) = *reinterpret_cast<const uint2*>(q8);
                         if ((pc & 3) == 0) a.hs[mc * (BN / 32) + col / 32] = sc;
                     }
-                } else if (mm < a.M) *reinterpret_cast<uint4*>(a.h + (int64_t)mm * BN + nb + pc * 8) = v;
+                } else if (mm < a.M) {
+                    typedef unsigned int nt_u32x4 __attribute__((ext_vector_type(4)));
+                    if (nt_io) __builtin_nontemporal_store(nt_u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_u32x4*>(a.h + (int64_t)mm * BN + nb + pc * 8));
+                    else *reinterpret_cast<uint4*>(a.h + (int64_t)mm * BN + nb + pc * 8) = v;
+                }
             }
         }
     }
@@ -226,7 +242,10 @@ static int launch_ln(const GemmLnArgs& a, hipStream_t st) {
     return 0;
 }
 
-int gemm_resid_ln(const GemmLnArgs& a, hipStream_t st) {
+int gemm_resid_ln(const GemmLnArgs& a0, hipStream_t st) {
+    static const int nt_env = getenv("RALD_NT_STORE") ? atoi(getenv("RALD_NT_STORE")) : 1;
+    GemmLnArgs a = a0;
+    a.nt_io = nt_env;
     RALD_CHECK(a.M > 0 && a.K > 0 && a.K % 64 == 0, "gemm_resid_ln: bad shape");
     RALD_CHECK(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.lda >= a.K && a.ldw >= a.K, "gemm_resid_ln: leading dimensions");
     RALD_CHECK(a.A && a.W && a.bias && a.x && (a.h || (a.h8 && a.hs)) && a.g && a.b && a.rows_per_group > 0, "gemm_resid_ln: null argument");

@@ -47,6 +47,7 @@ struct GemmLnArgs {
     bf16* h;                  // [M][512] bf16 out (skipped when h8 is set)
     unsigned char* h8 = nullptr;   // optional MXFP8 form of h instead: e4m3 [M][512] ...
     unsigned char* hs = nullptr;   // ... + e8m0 scales [M][16]
+    int nt_io = 1;                 // non-temporal residual / output traffic (RALD_NT_STORE=0 turns it off for A/B runs)
     const float* g; const float* b; int64_t gstride; int rows_per_group; float add_one, eps;
     int M, K;
 };
