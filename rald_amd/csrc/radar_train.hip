@@ -119,43 +119,54 @@ int im2col_t(const bf16* x, bf16* out, int B, int ID, int IH, int IW, int C, int
     return 0;
 }
 
-// conv_in (Cin = 1): dW[co][t] += sum_v dY[v][co] * cube[v + off(t)][0]; one block per 256 voxels, Cout <= 64
+// conv_in (Cin = 1): dW[co][t] += sum_v dY[v][co] * cube[v + off(t)][0].  A workgroup walks `chunks` tiles of 256
+// voxels (neighbourhoods staged in LDS), thread (co, tap group) keeps 7 partial sums, one atomicAdd per output per
+// workgroup.  Cout <= 64.
 __global__ __launch_bounds__(256) void conv_in_wgrad_kernel(const float* __restrict__ cube, int cube_ch, const float* __restrict__ dy, int B, int D, int H,
-                                                            int Wd, int Cout, float* __restrict__ dW) {
+                                                            int Wd, int Cout, int chunks, float* __restrict__ dW) {
     __shared__ float sx[256][28];
     const int64_t nvox = (int64_t)B * D * H * Wd;
-    const int64_t v0 = (int64_t)blockIdx.x * 256;
-    {
-        const int64_t v = v0 + threadIdx.x;
-        int w = 0, h = 0, d = 0;
-        int64_t b = 0;
-        if (v < nvox) { w = (int)(v % Wd); int64_t r = v / Wd; h = (int)(r % H); r /= H; d = (int)(r % D); b = r / D; }
-        for (int t = 0; t < 27; ++t) {
-            const int id = d + t / 9 - 1, ih = h + (t / 3) % 3 - 1, iw = w + t % 3 - 1;
-            float x = 0.f;
-            if (v < nvox && (unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)Wd)
-                x = cube[((((b * D + id) * H + ih) * Wd + iw)) * cube_ch];
-            sx[threadIdx.x][t] = x;
+    const int co = threadIdx.x & 63, g = threadIdx.x >> 6;
+    float acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int ch = 0; ch < chunks; ++ch) {
+        const int64_t v0 = ((int64_t)blockIdx.x * chunks + ch) * 256;
+        if (v0 >= nvox) break;
+        __syncthreads();
+        {
+            const int64_t v = v0 + threadIdx.x;
+            int w = 0, h = 0, d = 0;
+            int64_t b = 0;
+            if (v < nvox) { w = (int)(v % Wd); int64_t r = v / Wd; h = (int)(r % H); r /= H; d = (int)(r % D); b = r / D; }
+            for (int t = 0; t < 27; ++t) {
+                const int id = d + t / 9 - 1, ih = h + (t / 3) % 3 - 1, iw = w + t % 3 - 1;
+                float x = 0.f;
+                if (v < nvox && (unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)Wd)
+                    x = cube[((((b * D + id) * H + ih) * Wd + iw)) * cube_ch];
+                sx[threadIdx.x][t] = x;
+            }
+        }
+        __syncthreads();
+        if (co < Cout) {
+            const int vend = (int)(nvox - v0 < 256 ? nvox - v0 : 256);
+            for (int j = 0; j < vend; ++j) {
+                const float g_ = dy[(v0 + j) * Cout + co];
+#pragma unroll
+                for (int q = 0; q < 7; ++q) { const int t = g + 4 * q; if (t < 27) acc[q] += g_ * sx[j][t]; }
+            }
         }
     }
-    __syncthreads();
-    // thread -> (co = tid % 64, tap group = tid / 64: taps g, g+4, ...)
-    const int co = threadIdx.x & 63, g = threadIdx.x >> 6;
-    if (co >= Cout) return;
-    float acc[7] = {0, 0, 0, 0, 0, 0, 0};
-    const int64_t vend = nvox - v0 < 256 ? nvox - v0 : 256;
-    for (int j = 0; j < (int)vend; ++j) {
-        const float g_ = dy[(v0 + j) * Cout + co];
+    if (co < Cout) {
 #pragma unroll
-        for (int q = 0; q < 7; ++q) { const int t = g + 4 * q; if (t < 27) acc[q] += g_ * sx[j][t]; }
+        for (int q = 0; q < 7; ++q) { const int t = g + 4 * q; if (t < 27) atomicAdd(dW + co * 27 + t, acc[q]); }
     }
-#pragma unroll
-    for (int q = 0; q < 7; ++q) { const int t = g + 4 * q; if (t < 27) atomicAdd(dW + co * 27 + t, acc[q]); }
 }
 int conv_in_wgrad(const float* cube, int cube_ch, const float* dy, int B, int D, int H, int Wd, int Cout, float* dW, hipStream_t st) {
     RALD_CHECK(cube && dy && dW && Cout <= 64, "conv_in_wgrad: Cout must be <= 64");
     const int64_t nvox = (int64_t)B * D * H * Wd;
-    hipLaunchKernelGGL(conv_in_wgrad_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, cube, cube_ch, dy, B, D, H, Wd, Cout, dW);
+    const int64_t tiles = (nvox + 255) / 256;
+    const int chunks = (int)((tiles + 2047) / 2048);          // <= 2048 workgroups
+    hipLaunchKernelGGL(conv_in_wgrad_kernel, dim3((unsigned)((tiles + chunks - 1) / chunks)), dim3(256), 0, st, cube, cube_ch, dy, B, D, H, Wd, Cout,
+                       chunks, dW);
     RALD_HIP(hipGetLastError());
     return 0;
 }

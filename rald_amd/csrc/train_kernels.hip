@@ -200,22 +200,37 @@ int geglu_bwd(const bf16* u, const bf16* dhid, bf16* du, int64_t M, int I, hipSt
 }
 
 // ---- bias gradients: out[n] += sum_m X[m][n] (X f32 or bf16) ----------------------------------------------------
+// A workgroup covers `cw` columns (cw = min(N, 256) when that divides 256, else 256) and `rows_per_block` rows: the
+// 256 / cw row lanes stride over the rows, partials meet in LDS, one atomicAdd per column per workgroup (tall, narrow
+// inputs - a 64-channel bias over 2 M voxels - would otherwise serialise on 64 addresses).
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int64_t ld, int64_t M, int N, int rows_per_block, float* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= N) return;
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int64_t ld, int64_t M, int N, int cw, int rows_per_block,
+                                                     float* __restrict__ out) {
+    __shared__ float red[256];
+    const int tx = threadIdx.x % cw, ty = threadIdx.x / cw, nty = 256 / cw;
+    const int c = blockIdx.x * cw + tx;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
     float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) s += (float)X[r * ld + c];
-    atomicAdd(out + c, s);
+    if (c < N)
+        for (int64_t r = r0 + ty; r < r1; r += nty) s += (float)X[r * ld + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (ty == 0 && c < N) {
+        for (int k = 1; k < nty; ++k) s += red[k * cw + tx];
+        atomicAdd(out + c, s);
+    }
 }
 int colsum(const void* X, int is_bf16, int64_t ld, int64_t M, int N, float* out, hipStream_t st) {
     RALD_CHECK(M > 0 && N > 0 && X && out, "colsum: bad arguments");
-    const int rpb = M >= 4096 ? 32 : 16;           // enough row blocks to cover the chip (N is 512..4096 here)
-    dim3 grid(cdiv(N, 256), (unsigned)((M + rpb - 1) / rpb));
-    if (is_bf16) hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)X, ld, M, N, rpb, out);
-    else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)X, ld, M, N, rpb, out);
+    const int cw = (N < 256 && 256 % N == 0) ? N : 256;
+    const int col_blocks = cdiv(N, cw);
+    int64_t rpb = (M * col_blocks + 1023) / 1024;           // ~1024 workgroups in all
+    const int min_rows = 8 * (256 / cw);
+    if (rpb < min_rows) rpb = min_rows;
+    dim3 grid(col_blocks, (unsigned)((M + rpb - 1) / rpb));
+    if (is_bf16) hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)X, ld, M, N, cw, (int)rpb, out);
+    else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)X, ld, M, N, cw, (int)rpb, out);
     RALD_HIP(hipGetLastError());
     return 0;
 }
