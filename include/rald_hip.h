@@ -47,7 +47,7 @@ typedef struct rald_dit_config {
     int32_t enc_radar_ch;   /* 16   (configs.enc_radar_ch, :349)                        */
     int32_t radar_r, radar_a, radar_e; /* 128, 64, 32 input cube (R,A,E)                */
     float sigma_data;       /* 1.0 (:321)                                               */
-    int32_t qkv_dtype;      /* 0 = bf16 (default); 1 = MXFP8 e4m3 for the attention q/k/v projections (BASELINE config #5); 2 = also the GEGLU projection */
+    int32_t qkv_dtype;      /* 0 = bf16 (default); 1 = MXFP8 e4m3 for the attention q/k/v projections (BASELINE config #5); 2 = also the GEGLU projection; 3 = also ff.net.2 */
 } rald_dit_config;
 
 void rald_dit_default_config(rald_dit_config* cfg);

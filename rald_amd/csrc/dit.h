@@ -58,7 +58,8 @@ struct Dit {
         float *b_o, *b_o2, *b_ff1, *b_ff2;
         // MXFP8 copies of the attention projections (cfg.qkv_dtype == 1): e4m3 elements [rows][D] + e8m0 scales [rows][D/32]
         unsigned char *q8_qk = nullptr, *s8_qk = nullptr, *q8_v = nullptr, *s8_v = nullptr, *q8_q2 = nullptr, *s8_q2 = nullptr;
-        unsigned char *q8_ff1 = nullptr, *s8_ff1 = nullptr;   // qkv_dtype == 2: the GEGLU projection too (packed row order)
+        unsigned char *q8_ff1 = nullptr, *s8_ff1 = nullptr;   // qkv_dtype >= 2: the GEGLU projection too (packed row order)
+        unsigned char *q8_ff2 = nullptr, *s8_ff2 = nullptr;   // qkv_dtype == 3: and the feed-forward's output projection
     };
     std::vector<Layer> layers;
     bf16 *w_k2_all = nullptr, *w_v2_all = nullptr;      // attn2.to_k / to_v of every block stacked: [L*D, context_dim]
@@ -85,6 +86,7 @@ struct Dit {
     int ws_batch = 0;
     float *ws_x = nullptr, *ws_xcur = nullptr, *ws_xeul = nullptr, *ws_den = nullptr, *ws_dcur = nullptr;
     unsigned char *ws_h8 = nullptr, *ws_hs = nullptr;   // MXFP8 AdaLN outputs feeding q/k/v (qkv_dtype >= 1)
+    unsigned char *ws_g8 = nullptr, *ws_gs = nullptr;   // MXFP8 GEGLU output feeding ff.net.2 (qkv_dtype == 3)
     bf16 *ws_h = nullptr, *ws_qk = nullptr, *ws_vt = nullptr, *ws_o = nullptr, *ws_q2 = nullptr, *ws_g = nullptr, *ws_tok = nullptr;
 
     // live timing of the dominant kernel (the FF1 GEGLU GEMM) with HIP events on the launch stream

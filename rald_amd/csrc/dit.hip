@@ -95,7 +95,7 @@ int Dit::create() {
     const auto& c = cfg;
     D = c.n_heads * c.d_head;
     RALD_CHECK(c.d_head == 64, "dit: only d_head = 64 is implemented");
-    RALD_CHECK(c.qkv_dtype >= 0 && c.qkv_dtype <= 2, "dit: qkv_dtype must be 0 (bf16), 1 (MXFP8 q/k/v) or 2 (MXFP8 q/k/v + GEGLU projection)");
+    RALD_CHECK(c.qkv_dtype >= 0 && c.qkv_dtype <= 3, "dit: qkv_dtype must be 0 (bf16), 1 (MXFP8 q/k/v), 2 (+ GEGLU projection) or 3 (+ feed-forward output projection)");
     RALD_CHECK(D == 512, "dit: inner dim (n_heads*d_head) must be 512");
     RALD_CHECK(c.n_latents > 0 && c.n_latents % 64 == 0, "dit: n_latents must be a positive multiple of 64");
     RALD_CHECK(c.channels >= 1 && c.channels <= 64, "dit: channels must be in [1,64]");
@@ -124,7 +124,8 @@ int Dit::create() {
             l.q8_qk = U8((size_t)2 * D * D); l.s8_qk = U8((size_t)2 * D * D / 32);
             l.q8_v = U8((size_t)D * D);      l.s8_v = U8((size_t)D * D / 32);
             l.q8_q2 = U8((size_t)D * D);     l.s8_q2 = U8((size_t)D * D / 32);
-            if (c.qkv_dtype == 2) { l.q8_ff1 = U8((size_t)8 * D * D); l.s8_ff1 = U8((size_t)8 * D * D / 32); RALD_CHECK(l.q8_ff1 && l.s8_ff1, "dit: device allocation failed"); }
+            if (c.qkv_dtype >= 2) { l.q8_ff1 = U8((size_t)8 * D * D); l.s8_ff1 = U8((size_t)8 * D * D / 32); RALD_CHECK(l.q8_ff1 && l.s8_ff1, "dit: device allocation failed"); }
+            if (c.qkv_dtype == 3) { l.q8_ff2 = U8((size_t)4 * D * D); l.s8_ff2 = U8((size_t)4 * D * D / 32); RALD_CHECK(l.q8_ff2 && l.s8_ff2, "dit: device allocation failed"); }
             RALD_CHECK(l.q8_qk && l.s8_qk && l.q8_v && l.s8_v && l.q8_q2 && l.s8_q2,
                        "dit: device allocation failed");
         }
@@ -240,7 +241,8 @@ int Dit::finalize() {
             RALD_TRY(quantize_mx8(l.w_qk, 1, D, l.q8_qk, D, l.s8_qk, 2 * D, D, nullptr));
             RALD_TRY(quantize_mx8(l.w_v, 1, D, l.q8_v, D, l.s8_v, D, D, nullptr));
             RALD_TRY(quantize_mx8(l.w_q2, 1, D, l.q8_q2, D, l.s8_q2, D, D, nullptr));
-            if (cfg.qkv_dtype == 2) RALD_TRY(quantize_mx8(l.w_ff1, 1, D, l.q8_ff1, D, l.s8_ff1, 8 * D, D, nullptr));
+            if (cfg.qkv_dtype >= 2) RALD_TRY(quantize_mx8(l.w_ff1, 1, D, l.q8_ff1, D, l.s8_ff1, 8 * D, D, nullptr));
+            if (cfg.qkv_dtype == 3) RALD_TRY(quantize_mx8(l.w_ff2, 1, 4 * D, l.q8_ff2, 4 * D, l.s8_ff2, D, 4 * D, nullptr));
         }
         RALD_HIP(hipDeviceSynchronize());
     }
@@ -251,7 +253,7 @@ int Dit::finalize() {
 int Dit::reserve(int B) {
     if (B <= ws_batch) return 0;
     RALD_HIP(hipDeviceSynchronize());
-    for (void* p : {(void*)ws_h8, (void*)ws_hs})
+    for (void* p : {(void*)ws_h8, (void*)ws_hs, (void*)ws_g8, (void*)ws_gs})
         if (p) arena.release(p);
     for (void* p : {(void*)ws_x, (void*)ws_h, (void*)ws_qk, (void*)ws_vt, (void*)ws_o, (void*)ws_q2, (void*)ws_g, (void*)ws_tok,
                     (void*)ws_xcur, (void*)ws_xeul, (void*)ws_den, (void*)ws_dcur})
@@ -276,6 +278,11 @@ int Dit::reserve(int B) {
         ws_h8 = (unsigned char*)arena.alloc(M * D, true);
         ws_hs = (unsigned char*)arena.alloc(M * D / 32, true);
         RALD_CHECK(ws_h8 && ws_hs, "dit: workspace allocation failed");
+        if (cfg.qkv_dtype == 3) {
+            ws_g8 = (unsigned char*)arena.alloc(M * 4 * D, true);
+            ws_gs = (unsigned char*)arena.alloc(M * 4 * D / 32, true);
+            RALD_CHECK(ws_g8 && ws_gs, "dit: workspace allocation failed");
+        }
     }
     ws_batch = B;
     return 0;
@@ -459,10 +466,22 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
             a2.O = ws_o; a2.ldo = D; a2.strideO = (int64_t)NL * D;
             a2.nq = NL; a2.nk = T; a2.k_rows = T; a2.heads = cfg.n_heads; a2.batch = B; a2.scale = scale; a2.q_prescaled = 1;
             RALD_TRY(attention_d64(a2, st));
-            if (cfg.qkv_dtype == 2) {
+            // qkv_dtype 3: the GEGLU output leaves the FF1 epilogue as MXFP8 and ff.net.2 (+ residual + next AdaLN) consumes it
+            const bool ff2_mx = cfg.qkv_dtype == 3 && M % 256 == 0 && M >= 4096 && fuse_ln && gemm_resid_ln_pays(M, 4 * D);
+            if (cfg.qkv_dtype >= 2) {
                 RALD_TRY(resid_ln8(ws_o, D, l.w_o2, D, l.b_o2, D, m3));                  // + norm3 (MXFP8)
                 Mx8Args f1 = mx(ws_h8, ws_hs, l.q8_ff1, l.s8_ff1, ws_g, 4 * D, l.b_ff1, M, 8 * D);
+                if (ff2_mx) { f1.g.out8 = ws_g8; f1.g.outs = ws_gs; }
                 RALD_TRY(gemm_mx8(f1, EPI_GEGLU, st));
+                if (ff2_mx) {
+                    const float* mn = (li + 1 < L) ? mod + (int64_t)((li + 1) * 3) * 2 * D : m3;      // last block: the LN output is unused
+                    GemmLnArgs g;
+                    g.A = nullptr; g.W = nullptr; g.A8 = ws_g8; g.SA = ws_gs; g.W8 = l.q8_ff2; g.SW = l.s8_ff2; g.lda = 4 * D; g.ldw = 4 * D;
+                    g.bias = l.b_ff2; g.x = ws_x; g.h = nullptr; g.h8 = ws_h8; g.hs = ws_hs;
+                    g.g = mn; g.b = mn + D; g.gstride = gstride; g.rows_per_group = NL; g.add_one = 1.0f; g.eps = 1e-5f; g.M = M; g.K = 4 * D;
+                    RALD_TRY(gemm_resid_ln(g, st));
+                    continue;
+                }
             } else {
                 RALD_TRY(resid_ln(ws_o, D, l.w_o2, D, l.b_o2, D, m3));                   // + norm3 (bf16) for the feed-forward
                 GemmArgs f1 = gemm_args(ws_h, D, l.w_ff1, D, ws_g, 4 * D, l.b_ff1, M, 8 * D, D);

@@ -429,6 +429,11 @@ static int gemm_nt_impl(const GemmArgs& a, int epi, hipStream_t st) {
     } else {
         RALD_CHECK(a.ldc >= a.N, "gemm: ldc < N");
     }
+    if (a.out8) {
+        RALD_CHECK(epi == EPI_GEGLU && a.outs && a.batch * a.batch2 == 1 && a.M % 256 == 0 && a.N % 256 == 0 && (a.N / 2) % 32 == 0 &&
+                   (int64_t)(a.M / 256) * (a.N / 256) >= 256, "gemm: the MXFP8 output form needs the GEGLU epilogue on full 256x256 tiles");
+        return launch_glds<256, 256, 4, 2, 2>(a, epi, st);
+    }
     // engine selection.  Default (-1): LDS-DMA 256x256 tiles (8 waves) when they give every CU at
     // least one tile, LDS-DMA 128x128 (4 waves, 2 workgroups/CU) otherwise, register-staged 64x64 for
     // the small-M (batch-1) regime.  RALD_GEMM_IMPL forces a variant for A/B microbenchmarks:

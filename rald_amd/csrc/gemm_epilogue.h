@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 #include "kernels.h"
+#include "mx8.h"
 
 namespace rald {
 
@@ -61,6 +62,24 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[MT][NT], const Ge
             const uint4 v = *reinterpret_cast<const uint4*>(patch + r * STRIDE + pc * 16);
             constexpr int EPP = F32OUT ? 4 : 8;                           // elements per 16-byte piece
             const int c = oc0 + pc * EPP;
+            if constexpr (!F32OUT) {
+                if (a.out8) {
+                    // MXFP8 output (host contract: every lane of the wave is active here and the tile is full): this
+                    // lane's piece is 8 consecutive columns, 4 consecutive lanes = one 32-column block
+                    const bf16x8 hv = *reinterpret_cast<const bf16x8*>(&v);
+                    float f[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = (float)hv[e];
+                    unsigned char q8[8] __attribute__((aligned(8)));
+                    unsigned char sc;
+                    mx8_block(f, q8, &sc, true);
+                    if (m < a.M && c < ncols) {
+                        *reinterpret_cast<uint2*>(a.out8 + (int64_t)m * a.ldc + c) = *reinterpret_cast<const uint2*>(q8);
+                        if ((pc & 3) == 0) a.outs[(int64_t)m * (ncols / 32) + c / 32] = sc;
+                    }
+                    continue;
+                }
+            }
             if (m < a.M && c < ncols && !(a.ablate & 16)) {      // 16: diagnostics, no global stores
                 if constexpr (EPI == EPI_RESID) {
                     float* C = reinterpret_cast<float*>(a.C) + coff + (int64_t)m * a.ldc + c;

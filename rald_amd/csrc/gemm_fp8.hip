@@ -202,6 +202,8 @@ int gemm_mx8(const Mx8Args& a0, int epi, hipStream_t st) {
     else RALD_CHECK(g.ldc % 4 == 0 && g.ldc >= g.N, "gemm_mx8: ldc must be >= N and a multiple of 4");
     RALD_CHECK((int64_t)g.M * (g.K / 32) < ((int64_t)1 << 31) && (int64_t)g.N * (g.K / 32) < ((int64_t)1 << 31), "gemm_mx8: scale index overflow");
     a.g.ablate = 64;                           // streamed (non-temporal) bf16 output, as in gemm_nt
+    if (g.out8) RALD_CHECK(epi == EPI_GEGLU && g.outs && g.batch == 1 && g.M % 256 == 0 && g.N % 256 == 0 && (int64_t)(g.M / 256) * (g.N / 256) >= 256,
+                           "gemm_mx8: the MXFP8 output form needs the GEGLU epilogue on full 256x256 tiles");
     const int64_t wg256 = (int64_t)(g.M / 256) * (g.N / 256) * g.batch;
     if (g.M % 256 == 0 && g.N % 256 == 0 && wg256 >= 256) return launch_mx8<256, 256, 4, 2>(a, epi, st);
     return launch_mx8<128, 128, 2, 2>(a, epi, st);

@@ -25,7 +25,7 @@ namespace rald {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-template <int BM, int WM, int WN>
+template <int BM, int WM, int WN, bool MX>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs a) {
     constexpr int BN = 512, BK = 64, NSTAGE = 2;
     constexpr int WAVES = WM * WN;
@@ -49,24 +49,28 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs 
     const int m0 = blockIdx.x * BM;
     const int lr = lane >> 3;
     const int lc = (lane & 7) ^ lr;
-    const bf16* gA[CA];
-    const bf16* gB[CB];
+    // operand rows are 128 bytes per k-step in both forms: 64 bf16, or 128 e4m3 (MX: e4m3 + e8m0 per 32, see gemm_fp8.hip)
+    constexpr int ESZ = MX ? 1 : 2;
+    const unsigned char* A0 = MX ? a.A8 : reinterpret_cast<const unsigned char*>(a.A);
+    const unsigned char* W0 = MX ? a.W8 : reinterpret_cast<const unsigned char*>(a.W);
+    const unsigned char* gA[CA];
+    const unsigned char* gB[CB];
 #pragma unroll
     for (int p = 0; p < CA; ++p) {
         int r = m0 + 8 * (wave + WAVES * p) + lr;
         r = r < a.M ? r : a.M - 1;
-        gA[p] = a.A + (int64_t)r * a.lda + lc * 8;
+        gA[p] = A0 + ((int64_t)r * a.lda) * ESZ + lc * 16;
     }
 #pragma unroll
-    for (int p = 0; p < CB; ++p) gB[p] = a.W + (int64_t)(8 * (wave + WAVES * p) + lr) * a.ldw + lc * 8;
+    for (int p = 0; p < CB; ++p) gB[p] = W0 + ((int64_t)(8 * (wave + WAVES * p) + lr) * a.ldw) * ESZ + lc * 16;
     auto stage = [&](int kt, int buf) {
         unsigned char* base = smem + buf * STAGE_BYTES;
 #pragma unroll
         for (int p = 0; p < CA; ++p)
-            __builtin_amdgcn_global_load_lds((glb_void*)(gA[p] + kt * BK), (lds_void*)(base + (wave + WAVES * p) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(gA[p] + kt * 128), (lds_void*)(base + (wave + WAVES * p) * 1024), 16, 0, 0);
 #pragma unroll
         for (int p = 0; p < CB; ++p)
-            __builtin_amdgcn_global_load_lds((glb_void*)(gB[p] + kt * BK), (lds_void*)(base + BM * 128 + (wave + WAVES * p) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(gB[p] + kt * 128), (lds_void*)(base + BM * 128 + (wave + WAVES * p) * 1024), 16, 0, 0);
     };
 
     f32x4 acc[MT][NT];
@@ -74,8 +78,58 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs 
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int nk = a.K / BK;
+    const int nk = MX ? a.K / 128 : a.K / BK;
     const int fr = lane & 15, fq = lane >> 4;
+    if constexpr (MX) {
+        typedef int i32x8 __attribute__((ext_vector_type(8)));
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        const int kb = a.K / 32;
+        int offA[MT], offB[NT], sa_n[MT], sb_n[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            int r = m0 + wm * (BM / WM) + i * 16 + fr;
+            r = r < a.M ? r : a.M - 1;
+            offA[i] = r * kb + fq;
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) offB[j] = (wn * (BN / WN) + j * 16 + fr) * kb + fq;
+        auto load_scales = [&](int kt) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) sa_n[i] = a.SA[offA[i] + kt * 4];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) sb_n[j] = a.SW[offB[j] + kt * 4];
+        };
+        auto read_frag = [&](const unsigned char* tile_base, int row) -> i32x8 {
+            const i32x4* sp = reinterpret_cast<const i32x4*>(tile_base) + row * 8;
+            const i32x4 lo = sp[fq ^ (row & 7)], hi = sp[(fq + 4) ^ (row & 7)];
+            return i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        };
+        stage(0, 0);
+        load_scales(0);
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            int sa[MT], sb[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) sa[i] = sa_n[i];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) sb[j] = sb_n[j];
+            if (kt + 1 < nk) { stage(kt + 1, (kt + 1) & 1); load_scales(kt + 1); }
+            const unsigned char* tA = smem + (kt & 1) * STAGE_BYTES;
+            const unsigned char* tB = tA + BM * 128;
+            i32x8 fa[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[i] = read_frag(tA, wm * (BM / WM) + i * 16 + fr);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const i32x8 fb = read_frag(tB, wn * (BN / WN) + j * 16 + fr);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb, fa[i], acc[i][j], 0, 0, 0, sb[j], 0, sa[i]);
+            }
+        }
+    } else {
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -104,6 +158,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs 
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
+    }
     }
 
     const bool nt_io = a.nt_io != 0;
@@ -228,11 +283,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs 
     }
 }
 
-template <int BM, int WM, int WN>
+template <int BM, int WM, int WN, bool MX>
 static int launch_ln(const GemmLnArgs& a, hipStream_t st) {
     constexpr int smem = 2 * (BM + 512) * 64 * 2;
     static bool attr_set = false;
-    auto kern = gemm_resid_ln_kernel<BM, WM, WN>;
+    auto kern = gemm_resid_ln_kernel<BM, WM, WN, MX>;
     if (!attr_set) {
         RALD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
@@ -246,14 +301,18 @@ int gemm_resid_ln(const GemmLnArgs& a0, hipStream_t st) {
     static const int nt_env = getenv("RALD_NT_STORE") ? atoi(getenv("RALD_NT_STORE")) : 1;
     GemmLnArgs a = a0;
     a.nt_io = nt_env;
-    RALD_CHECK(a.M > 0 && a.K > 0 && a.K % 64 == 0, "gemm_resid_ln: bad shape");
-    RALD_CHECK(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.lda >= a.K && a.ldw >= a.K, "gemm_resid_ln: leading dimensions");
-    RALD_CHECK(a.A && a.W && a.bias && a.x && (a.h || (a.h8 && a.hs)) && a.g && a.b && a.rows_per_group > 0, "gemm_resid_ln: null argument");
-    RALD_CHECK(((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.W % 16 == 0) && ((uintptr_t)a.x % 16 == 0) && ((uintptr_t)a.h % 16 == 0) &&
-               ((uintptr_t)a.g % 16 == 0) && ((uintptr_t)a.b % 16 == 0) && a.gstride % 4 == 0, "gemm_resid_ln: 16-byte alignment");
+    const bool mx = a.A8 != nullptr;                         // MXFP8 operands: A8/SA and W8/SW instead of A and W
+    RALD_CHECK(a.M > 0 && a.K > 0 && a.K % (mx ? 128 : 64) == 0, "gemm_resid_ln: bad shape");
+    RALD_CHECK(a.lda % 16 == 0 && a.ldw % 16 == 0 && a.lda >= a.K && a.ldw >= a.K, "gemm_resid_ln: leading dimensions");
+    RALD_CHECK((mx ? (a.SA && a.W8 && a.SW) : (a.A && a.W)) && a.bias && a.x && (a.h || (a.h8 && a.hs)) && a.g && a.b && a.rows_per_group > 0,
+               "gemm_resid_ln: null argument");
+    RALD_CHECK(((uintptr_t)a.A % 16 == 0) && ((uintptr_t)a.W % 16 == 0) && ((uintptr_t)a.A8 % 16 == 0) && ((uintptr_t)a.W8 % 16 == 0) &&
+               ((uintptr_t)a.x % 16 == 0) && ((uintptr_t)a.h % 16 == 0) && ((uintptr_t)a.g % 16 == 0) && ((uintptr_t)a.b % 16 == 0) &&
+               a.gstride % 4 == 0, "gemm_resid_ln: 16-byte alignment");
+    RALD_CHECK(!mx || (int64_t)a.M * (a.K / 32) < ((int64_t)1 << 31), "gemm_resid_ln: scale index overflow");
     // 128-row tiles (all 160 KiB of LDS) when they cover the chip, 64-row tiles for smaller M
-    if (cdiv(a.M, 128) >= 192) return launch_ln<128, 2, 4>(a, st);
-    return launch_ln<64, 1, 8>(a, st);
+    if (cdiv(a.M, 128) >= 192) return mx ? launch_ln<128, 2, 4, true>(a, st) : launch_ln<128, 2, 4, false>(a, st);
+    return mx ? launch_ln<64, 1, 8, true>(a, st) : launch_ln<64, 1, 8, false>(a, st);
 }
 
 }  // namespace rald

@@ -19,6 +19,8 @@ struct GemmArgs {
     // operand offset = b1 * stride + b2 * stride2
     int batch2 = 1;
     int64_t strideA2 = 0, strideB2 = 0, strideC2 = 0;
+    // optional MXFP8 form of a bf16 / GEGLU output INSTEAD of C: e4m3 [M][ldc] + e8m0 scales [M][ncols/32] (batch 1 only)
+    unsigned char *out8 = nullptr, *outs = nullptr;
 };
 #ifdef __HIPCC__
 __device__ __forceinline__ void gemm_batch_offsets(const GemmArgs& a, int bz, int64_t& oa, int64_t& ob, int64_t& oc) {
@@ -48,6 +50,8 @@ struct GemmLnArgs {
     unsigned char* h8 = nullptr;   // optional MXFP8 form of h instead: e4m3 [M][512] ...
     unsigned char* hs = nullptr;   // ... + e8m0 scales [M][16]
     int nt_io = 1;                 // non-temporal residual / output traffic (RALD_NT_STORE=0 turns it off for A/B runs)
+    // MXFP8 operands instead of A / W when A8 is set: e4m3 [M][K], [512][K] + e8m0 scales [..][K/32]; lda/ldw in elements
+    const unsigned char *A8 = nullptr, *SA = nullptr, *W8 = nullptr, *SW = nullptr;
     const float* g; const float* b; int64_t gstride; int rows_per_group; float add_one, eps;
     int M, K;
 };

@@ -75,9 +75,9 @@ class _HipBacked(nn.Module):
 # LatentArrayTransformer (:171-233)
 # ----------------------------------------------------------------------------------------------
 def _qkv_code(name: str) -> int:
-    codes = {"bf16": 0, "fp8": 1, "fp8_ff1": 2}
+    codes = {"bf16": 0, "fp8": 1, "fp8_ff1": 2, "fp8_ff": 3}
     if name not in codes:
-        raise ValueError("qkv_dtype must be 'bf16', 'fp8' (MXFP8 q/k/v) or 'fp8_ff1' (MXFP8 q/k/v + GEGLU projection)")
+        raise ValueError("qkv_dtype must be 'bf16', 'fp8' (MXFP8 q/k/v), 'fp8_ff1' (+ GEGLU projection) or 'fp8_ff' (+ whole feed-forward)")
     return codes[name]
 
 
