@@ -148,8 +148,9 @@ def edm_sampler(net, latents, class_labels=None, cond_type=None, randn_like=torc
 
 
 class EDMLoss:
-    """:277-295.  Forward value only in this round (the backward/optimizer path is SURVEY.md
-    §8f rank 1, 'next')."""
+    """:277-295, the reference's call signature and value (forward through the HIP denoiser).  Training - the same loss with
+    its backward pass, clip / AdamW / EMA - goes through ``rald_amd.train_dit.EdmTrainer``, which takes the two random
+    draws explicitly."""
 
     def __init__(self, P_mean=-1.2, P_std=1.2, sigma_data=1):
         self.P_mean, self.P_std, self.sigma_data = P_mean, P_std, sigma_data

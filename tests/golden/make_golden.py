@@ -239,6 +239,8 @@ def main():
         golden_queries()
     if want("g12"):
         golden_optim()
+    if "g13" in only:                      # ~1 min of CPU; not part of the default set
+        golden_sample1000()
     print(f"done in {time.time() - t00:.0f}s")
 
 
@@ -392,6 +394,19 @@ def golden_optim():
     out.update({f"m{i}": st[i]["exp_avg"] for i in range(len(params))})
     out.update({f"v{i}": st[i]["exp_avg_sq"] for i in range(len(params))})
     save("g12_optim.npz", norms=np.array(norms, np.float64), **out)
+
+
+def golden_sample1000():
+    """G13 (BASELINE config #5: 1000-step sampler = 1999 NFE): depth-2 model, B = 1.  Generated with the CPU ORACLE
+    (oracle/rald_oracle.py, itself pinned to the reference by G1-G4), not with the reference's sampler: the reference
+    re-runs the 287-GFLOP radar encoder inside every NFE, ~2 000 s for this vector, and hoisting it
+    is bit-identical (verified on G4)."""
+    from oracle import rald_oracle as O
+    sd = weights.make_state_dict(weights.dit_spec(depth=2), 0)
+    with torch.no_grad():
+        cond = O.process_radar_cond(sd, synth.radar_cube(1))
+        s = O.edm_sampler(lambda xx, ss: O.edm_precond(sd, xx, ss, cond, depth=2), synth.latents([0]), num_steps=1000)
+    save("g13_sample1000_oracle.npz", sample=s)
 
 
 if __name__ == "__main__":
