@@ -121,12 +121,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs 
             i32x8 fa[MT];
 #pragma unroll
             for (int i = 0; i < MT; ++i) fa[i] = read_frag(tA, wm * (BM / WM) + i * 16 + fr);
+            i32x8 fb = read_frag(tB, wn * (BN / WN) + fr);          // one n-tile ahead of its MFMAs
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const i32x8 fb = read_frag(tB, wn * (BN / WN) + j * 16 + fr);
+                i32x8 fb_next = fb;
+                if (j + 1 < NT) fb_next = read_frag(tB, wn * (BN / WN) + (j + 1) * 16 + fr);
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
                     acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb, fa[i], acc[i][j], 0, 0, 0, sb[j], 0, sa[i]);
+                fb = fb_next;
             }
         }
     } else {
