@@ -36,10 +36,10 @@ struct Ae {
     }
     // latent-stack workspace
     int dec_batch = 0;
-    float* x_x = nullptr;
+    float *x_x = nullptr, *x_part = nullptr;   // x_part: split-K partial sums of the small-batch FF2 (norm.hip resid_splitk_ln)
     bf16 *x_h = nullptr, *x_qk = nullptr, *x_vt = nullptr, *x_o = nullptr, *x_g = nullptr, *x_kd = nullptr;
     std::vector<void**> dec_ptrs() {
-        return {(void**)&x_x, (void**)&x_h, (void**)&x_qk, (void**)&x_vt, (void**)&x_o, (void**)&x_g, (void**)&x_kd};
+        return {(void**)&x_x, (void**)&x_part, (void**)&x_h, (void**)&x_qk, (void**)&x_vt, (void**)&x_o, (void**)&x_g, (void**)&x_kd};
     }
     // query workspace (one chunk)
     int64_t q_rows = 0;

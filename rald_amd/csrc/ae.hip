@@ -342,6 +342,7 @@ int Ae::reserve_decode(int B) {
     for (void** p : dec_ptrs()) if (*p) { arena.release(*p); *p = nullptr; }
     const size_t M = cfg.num_latents, b = B;
     x_x = (float*)arena.alloc(b * M * d * 4, true);
+    x_part = (float*)arena.alloc((size_t)4 * (b * M < 2048 ? b * M : 2048) * 512 * 4, true);
     x_h = (bf16*)arena.alloc(b * M * d * 2, true);
     x_qk = (bf16*)arena.alloc(b * M * 2 * I * 2, true);
     x_vt = (bf16*)arena.alloc(b * I * M * 2, true);
@@ -368,6 +369,8 @@ int Ae::decode_latents(const float* z, int B, void* ctx, hipStream_t st) {
     static const bool fuse_env = !(getenv("RALD_FUSE_LN") && atoi(getenv("RALD_FUSE_LN")) == 0);
     const bool fuse_ok = fuse_env && d == 512;                              // the fused epilogue owns whole 512-wide rows
     auto resid_ln = [&](const bf16* A, int64_t lda, const bf16* W, int64_t ldw, const float* bias, int K, const float* ng, const float* nb) -> int {
+        if (d == 512 && splitk_for(BM, K))
+            return resid_splitk_ln(A, lda, W, ldw, bias, x_x, x_h, ng, nb, 0, 1 << 30, 0.f, 1e-5f, BM, K, splitk_for(BM, K), x_part, st);
         if (fuse_ok && gemm_resid_ln_pays(BM, K)) {
             GemmLnArgs g;
             g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.x = x_x; g.h = x_h;

@@ -84,6 +84,7 @@ struct Dit {
     int64_t mod_row() const { return (int64_t)cfg.depth * 3 * 2 * D; }
     // activation workspace
     int ws_batch = 0;
+    float* ws_part = nullptr;   // split-K partial sums of the small-batch FF2 (norm.hip resid_splitk_ln)
     float *ws_x = nullptr, *ws_xcur = nullptr, *ws_xeul = nullptr, *ws_den = nullptr, *ws_dcur = nullptr;
     unsigned char *ws_h8 = nullptr, *ws_hs = nullptr;   // MXFP8 AdaLN outputs feeding q/k/v (qkv_dtype >= 1)
     unsigned char *ws_g8 = nullptr, *ws_gs = nullptr;   // MXFP8 GEGLU output feeding ff.net.2 (qkv_dtype == 3)

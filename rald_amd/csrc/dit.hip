@@ -253,7 +253,7 @@ int Dit::finalize() {
 int Dit::reserve(int B) {
     if (B <= ws_batch) return 0;
     RALD_HIP(hipDeviceSynchronize());
-    for (void* p : {(void*)ws_h8, (void*)ws_hs, (void*)ws_g8, (void*)ws_gs})
+    for (void* p : {(void*)ws_h8, (void*)ws_hs, (void*)ws_g8, (void*)ws_gs, (void*)ws_part})
         if (p) arena.release(p);
     for (void* p : {(void*)ws_x, (void*)ws_h, (void*)ws_qk, (void*)ws_vt, (void*)ws_o, (void*)ws_q2, (void*)ws_g, (void*)ws_tok,
                     (void*)ws_xcur, (void*)ws_xeul, (void*)ws_den, (void*)ws_dcur})
@@ -267,6 +267,7 @@ int Dit::reserve(int B) {
     ws_o = (bf16*)arena.alloc(M * D * 2, true);
     ws_q2 = (bf16*)arena.alloc(M * D * 2, true);
     ws_g = (bf16*)arena.alloc(M * 4 * D * 2, true);
+    ws_part = (float*)arena.alloc((size_t)4 * (M < 2048 ? M : 2048) * 512 * 4, true);
     ws_tok = (bf16*)arena.alloc((size_t)B * cfg.n_cond_tokens * cfg.context_dim * 2, true);
     ws_xcur = (float*)arena.alloc(nl * 4, true);
     ws_xeul = (float*)arena.alloc(nl * 4, true);
@@ -397,6 +398,9 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
     static const bool fuse_ln = !(getenv("RALD_FUSE_LN") && atoi(getenv("RALD_FUSE_LN")) == 0);
     auto resid_ln = [&](const bf16* A, int64_t lda, const bf16* W, int64_t ldw, const float* bias, int K, const float* mnext) -> int {
         // x += A.W^T + bias, then (if mnext) h = AdaLN(x; mnext) for the next sub-block
+        if (splitk_for(M, K))
+            return resid_splitk_ln(A, lda, W, ldw, bias, ws_x, mnext ? ws_h : nullptr, mnext, mnext ? mnext + D : nullptr, gstride, NL, 1.0f, 1e-5f,
+                                   M, K, splitk_for(M, K), ws_part, st);
         if (fuse_ln && mnext && gemm_resid_ln_pays(M, K)) {
             GemmLnArgs g;
             g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.x = ws_x; g.h = ws_h;

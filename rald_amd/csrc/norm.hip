@@ -63,6 +63,64 @@ int layernorm_mod(const float* x, bf16* out, int M, int D, const float* g, const
     return 0;
 }
 
+// ---- split-K tail for small-M residual GEMMs: x += bias + sum_s part[s]; h = LN(x)*(add_one+g)+b (optional) ---------------
+// At M <= 2048 rows a [M,512] x K = 2048 product has only a few dozen 64x64 tiles, each walking the whole K; splitting K over
+// the batch dimension fills the chip, and this kernel is the (deterministic) reduction, fused with the residual add and the
+// following LayerNorm - one launch instead of LayerNorm's own.  D = 512, one wave per row.
+__global__ __launch_bounds__(256) void reduce_resid_ln_kernel(const float* __restrict__ part, int S, int64_t part_stride, const float* __restrict__ bias,
+                                                              float* __restrict__ x, bf16* __restrict__ h, int M, const float* __restrict__ g,
+                                                              const float* __restrict__ b, int64_t gstride, int rows_per_group, float add_one, float eps) {
+    constexpr int D = 512;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float v[8];
+    {
+        const float4 a0 = *reinterpret_cast<const float4*>(x + (int64_t)row * D + lane * 8), a1 = *reinterpret_cast<const float4*>(x + (int64_t)row * D + lane * 8 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(bias + lane * 8), b1 = *reinterpret_cast<const float4*>(bias + lane * 8 + 4);
+        v[0] = a0.x + b0.x; v[1] = a0.y + b0.y; v[2] = a0.z + b0.z; v[3] = a0.w + b0.w;
+        v[4] = a1.x + b1.x; v[5] = a1.y + b1.y; v[6] = a1.z + b1.z; v[7] = a1.w + b1.w;
+    }
+    for (int s = 0; s < S; ++s) {
+        const float* p = part + s * part_stride + (int64_t)row * D + lane * 8;
+        const float4 p0 = *reinterpret_cast<const float4*>(p), p1 = *reinterpret_cast<const float4*>(p + 4);
+        v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w; v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
+    }
+    *reinterpret_cast<float4*>(x + (int64_t)row * D + lane * 8) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(x + (int64_t)row * D + lane * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    if (!h) return;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sum += v[i];
+    const float mean = wave_sum(sum) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[i] -= mean; q += v[i] * v[i]; }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / D) + eps);
+    const int64_t goff = (int64_t)(row / rows_per_group) * gstride;
+    const float4 g0 = *reinterpret_cast<const float4*>(g + goff + lane * 8), g1 = *reinterpret_cast<const float4*>(g + goff + lane * 8 + 4);
+    const float4 c0 = *reinterpret_cast<const float4*>(b + goff + lane * 8), c1 = *reinterpret_cast<const float4*>(b + goff + lane * 8 + 4);
+    bf16x4* o = reinterpret_cast<bf16x4*>(h + (int64_t)row * D + lane * 8);
+    o[0] = pack4(v[0] * rstd * (add_one + g0.x) + c0.x, v[1] * rstd * (add_one + g0.y) + c0.y, v[2] * rstd * (add_one + g0.z) + c0.z,
+                 v[3] * rstd * (add_one + g0.w) + c0.w);
+    o[1] = pack4(v[4] * rstd * (add_one + g1.x) + c1.x, v[5] * rstd * (add_one + g1.y) + c1.y, v[6] * rstd * (add_one + g1.z) + c1.z,
+                 v[7] * rstd * (add_one + g1.w) + c1.w);
+}
+
+// x[M][512] += A[M][K].W[512][K]^T + bias (K split over `splits` batch entries into `scratch` [splits][M][512] f32), then the LayerNorm
+int resid_splitk_ln(const bf16* A, int64_t lda, const bf16* W, int64_t ldw, const float* bias, float* x, bf16* h, const float* g, const float* b,
+                    int64_t gstride, int rows_per_group, float add_one, float eps, int M, int K, int splits, float* scratch, hipStream_t st) {
+    RALD_CHECK(splits >= 1 && splits <= 16 && K % (splits * 64) == 0 && scratch && bias && x, "resid_splitk_ln: bad arguments");
+    RALD_CHECK(!h || (g && b && rows_per_group > 0), "resid_splitk_ln: LayerNorm parameters missing");
+    GemmArgs p = gemm_args(A, lda, W, ldw, scratch, 512, nullptr, M, 512, K / splits);
+    p.batch = splits; p.strideA = K / splits; p.strideB = K / splits; p.strideC = (int64_t)M * 512;
+    RALD_TRY(gemm_nt(p, EPI_F32, st));
+    hipLaunchKernelGGL(reduce_resid_ln_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, scratch, splits, (int64_t)M * 512, bias, x, h, M, g, b, gstride,
+                       rows_per_group, add_one, eps);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
 // ---- proj_in: K = C (latent channels, <= 64) is far too small for MFMA; fp32 FMA, 8 rows per WG.
 __global__ __launch_bounds__(256) void proj_in_kernel(const float* __restrict__ xin, const float* __restrict__ W,
                                                       float* __restrict__ x, int M, int C, int D,
