@@ -67,7 +67,9 @@ def test_transformer_context_dim_1024_vs_reference_golden():
 
 def test_batch_independence_and_b1():
     """Samples are independent (no cross-sample op on the path): a B=1 launch must agree with the
-    matching row of a B=5 launch (tile choice differs with M, so fp32-noise, not bitwise)."""
+    matching row of a B=5 launch.  Not bitwise: B=1 runs the launch-bound variants (LayerNorm in the GEMM prologue, split-K
+    FF2, 64x64 tiles), B=5 the throughput ones, and their bf16 roundings of h / accumulation orders differ - the bound is
+    the same order as either path's distance to the fp32 oracle (4e-3 at depth 2)."""
     from rald_amd import synth
     m, _ = _transformer(2)
     x = synth.latents(range(5)).cuda()
@@ -75,4 +77,4 @@ def test_batch_independence_and_b1():
     t = torch.tensor([0.1])
     full = m(x, t, cond=cond)
     one = m(x[3:4], t, cond=cond[3:4])
-    assert rel_l2(one, full[3:4]) < 2e-3
+    assert rel_l2(one, full[3:4]) < 4e-3
