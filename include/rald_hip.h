@@ -318,6 +318,11 @@ int rald_op_attention(const void* Q, int64_t ldq, int64_t strideQ, const void* K
                       int32_t nq, int32_t nk, int32_t k_rows, int32_t heads, int32_t batch, float scale, void* stream);
 /* fused residual GEMM + next LayerNorm (N = 512): x[M][512] += A[M][K].W[512][K]^T + bias (fp32, in place);
  * h_bf16 = LayerNorm(x) * (add_one + g[row/rows_per_group*gstride + c]) + b[...] */
+/* rald_op_attention with V row-major like K (V[b][j][h*64+d], e.g. a column slice of a fused q|k|v projection): the kernel
+ * transposes it on the LDS read (ds_read_b64_tr_b16).  nk % 64 == 0. */
+int rald_op_attention_vrow(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK, const void* V, int64_t ldv,
+                           int64_t strideV, void* O, int64_t ldo, int64_t strideO, int32_t nq, int32_t nk, int32_t heads, int32_t batch, float scale,
+                           void* stream);
 int rald_op_gemm_resid_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* x, void* h_bf16,
                           const float* g, const float* b, int64_t gstride, int32_t rows_per_group, float add_one, float eps,
                           int32_t M, int32_t K, void* stream);

@@ -235,6 +235,16 @@ def op_attention(Q: torch.Tensor, K: torch.Tensor, Vt: torch.Tensor, nk: int, he
     return O
 
 
+def op_attention_vrow(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+    """Q [B,nq,H*64], K / V [B,nk,H*64] (bf16, possibly column slices of one fused buffer) -> O [B,nq,H*64] bf16."""
+    Bn, nq, HD = Q.shape
+    O = torch.empty(Bn, nq, HD, device=Q.device, dtype=torch.bfloat16)
+    check(lib().rald_op_attention_vrow(C.c_void_p(_ptr(Q)), Q.stride(1), Q.stride(0), C.c_void_p(_ptr(K)), K.stride(1), K.stride(0),
+                                       C.c_void_p(_ptr(V)), V.stride(1), V.stride(0), C.c_void_p(_ptr(O)), O.stride(1), O.stride(0),
+                                       nq, K.shape[1], heads, Bn, scale, C.c_void_p(_stream())))
+    return O
+
+
 class AeHandle:
     """rald_ae*: encode / decode_latents / decode_queries of the set-latent autoencoder."""
 

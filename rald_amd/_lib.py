@@ -120,6 +120,8 @@ SIGNATURES = {
     "rald_op_layernorm": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_i64, c_int, c_float, c_float, c_void_p]),
     "rald_op_attention": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64,
                                   c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "rald_op_attention_vrow": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64,
+                                       c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "rald_op_gemm_resid_ln": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int,
                                       c_float, c_float, c_int, c_int, c_void_p]),
     "rald_op_cast_bf16": (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),

@@ -371,6 +371,17 @@ int rald_op_attention(const void* Q, int64_t ldq, int64_t strideQ, const void* K
     if (const char* e = getenv("RALD_ATTN_PRESCALED")) a.q_prescaled = atoi(e);   // timing experiments only
     return attention_d64(a, (hipStream_t)stream);
 }
+int rald_op_attention_vrow(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK, const void* V, int64_t ldv,
+                           int64_t strideV, void* O, int64_t ldo, int64_t strideO, int32_t nq, int32_t nk, int32_t heads, int32_t batch, float scale,
+                           void* stream) {
+    RALD_CHECK(Q && K && V && O, "rald_op_attention_vrow: null pointer");
+    AttnArgs a;
+    a.Q = (const bf16*)Q; a.ldq = ldq; a.strideQ = strideQ; a.K = (const bf16*)K; a.ldk = ldk; a.strideK = strideK;
+    a.Vt = nullptr; a.ldvt = 0; a.strideVt = 0; a.V = (const bf16*)V; a.ldv = ldv; a.strideV = strideV;
+    a.O = (bf16*)O; a.ldo = ldo; a.strideO = strideO;
+    a.nq = nq; a.nk = nk; a.k_rows = nk; a.heads = heads; a.batch = batch; a.scale = scale; a.q_prescaled = 0;
+    return attention_d64(a, (hipStream_t)stream);
+}
 int rald_op_gemm_resid_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* x, void* h_bf16,
                           const float* g, const float* b, int64_t gstride, int32_t rows_per_group, float add_one, float eps,
                           int32_t M, int32_t K, void* stream) {

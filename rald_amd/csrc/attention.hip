@@ -32,7 +32,7 @@ typedef const __attribute__((address_space(1))) void glb_void;
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-template <bool PRESCALED>
+template <bool PRESCALED, bool VROW>
 __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
     constexpr int TILE_BYTES = 64 * 128;                       // 64 rows x 128 B (K: keys x d, Vt: d x keys)
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE_BYTES];   // [buf][K | Vt]
@@ -57,14 +57,22 @@ __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
         const int row = 8 * (wave + 4 * p) + lr;
         const int lc = (lane & 7) ^ ((row >> 1) & 7);
         gK[p] = a.K + (int64_t)b * a.strideK + (int64_t)row * a.ldk + h * 64 + lc * 8;
-        gV[p] = a.Vt + (int64_t)b * a.strideVt + (int64_t)(h * 64 + row) * a.ldvt + lc * 8;
+        if constexpr (VROW) {
+            // V tile = [64 keys][64 d] like K, but read only through transposed 4x16 blocks (4 consecutive keys x 16 d):
+            // swizzle chunk ^ 4 on rows with bit 1 set, so that the two row pairs of a block fall into different halves of
+            // the 128-byte row (rows r and r+2 share a bank row)
+            const int lcv = (lane & 7) ^ ((row & 2) << 1);
+            gV[p] = a.V + (int64_t)b * a.strideV + (int64_t)row * a.ldv + h * 64 + lcv * 8;
+        } else {
+            gV[p] = a.Vt + (int64_t)b * a.strideVt + (int64_t)(h * 64 + row) * a.ldvt + lc * 8;
+        }
     }
     auto stage = [&](int j0, int buf) {
         unsigned char* base = smem + buf * 2 * TILE_BYTES;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             __builtin_amdgcn_global_load_lds((glb_void*)(gK[p] + (int64_t)j0 * a.ldk), (lds_void*)(base + (wave + 4 * p) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_void*)(gV[p] + j0), (lds_void*)(base + TILE_BYTES + (wave + 4 * p) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(gV[p] + (VROW ? (int64_t)j0 * a.ldv : (int64_t)j0)), (lds_void*)(base + TILE_BYTES + (wave + 4 * p) * 1024), 16, 0, 0);
         }
     };
 
@@ -190,10 +198,28 @@ __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
                 const int ch = 4 * u + 2 * s;                  // 8-key chunk holding keys 32u+16s .. +7
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    const int vrow = 32 * dt + r;
-                    const unsigned char* vr = sV + vrow * 128 + 8 * hf;
-                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vr + ((ch ^ ((vrow >> 1) & 7)) << 4));
-                    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vr + (((ch + 1) ^ ((vrow >> 1) & 7)) << 4));
+                    bf16x4 lo, hi;
+                    if constexpr (VROW) {
+                        // ds_read_b64_tr_b16: per 16-lane group, lane 4q+p supplies row (key) q, columns 4p..4p+3 of a 4x16 block and
+                        // lane i receives column i of the 4 rows.  Group g: d columns 32dt + 16(g&1) + i, keys 32u + 16s + 4(g>>1) + q
+                        // (lo) and + 8 (hi) - exactly the element order of the P fragment above.
+                        typedef short s16x4 __attribute__((ext_vector_type(4)));
+                        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                        const int gq = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+                        const int krow = 32 * u + 16 * s + 4 * (gq >> 1) + qq;
+                        const int lch = 4 * dt + 2 * (gq & 1) + (pp >> 1);
+                        const unsigned char* p_lo = sV + krow * 128 + ((lch ^ ((krow & 2) << 1)) << 4) + 8 * (pp & 1);
+                        const unsigned char* p_hi = sV + (krow + 8) * 128 + ((lch ^ (((krow + 8) & 2) << 1)) << 4) + 8 * (pp & 1);
+                        const s16x4 l4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p_lo);
+                        const s16x4 h4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p_hi);
+                        lo = __builtin_bit_cast(bf16x4, l4);
+                        hi = __builtin_bit_cast(bf16x4, h4);
+                    } else {
+                        const int vrow = 32 * dt + r;
+                        const unsigned char* vr = sV + vrow * 128 + 8 * hf;
+                        lo = *reinterpret_cast<const bf16x4*>(vr + ((ch ^ ((vrow >> 1) & 7)) << 4));
+                        hi = *reinterpret_cast<const bf16x4*>(vr + (((ch + 1) ^ ((vrow >> 1) & 7)) << 4));
+                    }
                     const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                     if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o0, 0, 0, 0);
                     else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o1, 0, 0, 0);
@@ -233,13 +259,24 @@ __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
 int attention_d64(const AttnArgs& a, hipStream_t st) {
     RALD_CHECK(a.nq > 0 && a.nk > 0 && a.heads > 0 && a.batch > 0, "attention: empty problem");
     RALD_CHECK(a.nq % 32 == 0, "attention: nq must be a multiple of 32");
-    RALD_CHECK(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldvt % 8 == 0 && a.ldo % 8 == 0, "attention: leading dimensions must be multiples of 8 elements (16-byte rows)");
+    RALD_CHECK(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldo % 8 == 0, "attention: leading dimensions must be multiples of 8 elements (16-byte rows)");
     RALD_CHECK(a.k_rows >= round_up(a.nk, 64), "attention: K must have rows allocated up to a multiple of 64 keys (the tail tile is staged whole)");
-    RALD_CHECK(a.ldvt >= round_up(a.nk, 64), "attention: Vt rows must be padded (finite values) to a multiple of 64 keys");
-    RALD_CHECK(((uintptr_t)a.Q % 16 == 0) && ((uintptr_t)a.K % 16 == 0) && ((uintptr_t)a.Vt % 16 == 0) && ((uintptr_t)a.O % 16 == 0), "attention: pointers must be 16-byte aligned");
+    RALD_CHECK(((uintptr_t)a.Q % 16 == 0) && ((uintptr_t)a.K % 16 == 0) && ((uintptr_t)a.O % 16 == 0), "attention: pointers must be 16-byte aligned");
+    const bool vrow = a.V != nullptr;
+    if (vrow) {
+        RALD_CHECK(a.Vt == nullptr && a.nk % 64 == 0 && a.ldv % 8 == 0 && (uintptr_t)a.V % 16 == 0, "attention: row-major V needs nk % 64 == 0 and 16-byte rows");
+    } else {
+        RALD_CHECK(a.Vt && a.ldvt % 8 == 0 && (uintptr_t)a.Vt % 16 == 0, "attention: Vt must be 16-byte aligned with 16-byte rows");
+        RALD_CHECK(a.ldvt >= round_up(a.nk, 64), "attention: Vt rows must be padded (finite values) to a multiple of 64 keys");
+    }
     dim3 grid(cdiv(a.nq, 128), a.heads, a.batch);
-    if (a.q_prescaled) hipLaunchKernelGGL(attention_d64_kernel<true>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(attention_d64_kernel<false>, grid, dim3(256), 0, st, a);
+    if (a.q_prescaled) {
+        if (vrow) hipLaunchKernelGGL((attention_d64_kernel<true, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attention_d64_kernel<true, false>), grid, dim3(256), 0, st, a);
+    } else {
+        if (vrow) hipLaunchKernelGGL((attention_d64_kernel<false, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((attention_d64_kernel<false, false>), grid, dim3(256), 0, st, a);
+    }
     RALD_HIP(hipGetLastError());
     return 0;
 }

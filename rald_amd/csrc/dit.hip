@@ -108,8 +108,8 @@ int Dit::create() {
     auto B16 = [&](size_t n) { return (bf16*)arena.alloc(n * 2, true); };
     auto F32 = [&](size_t n) { return (float*)arena.alloc(n * 4, true); };
     for (auto& l : layers) {
-        l.w_qk = B16((size_t)2 * D * D);
-        l.w_v = B16((size_t)D * D);
+        l.w_qk = B16((size_t)3 * D * D);                 // to_q | to_k | to_v stacked: one [1536, 512] projection
+        l.w_v = l.w_qk + (size_t)2 * D * D;              // (alias: rows 1024..1535)
         l.w_o = B16((size_t)D * D);
         l.b_o = F32(D);
         l.w_q2 = B16((size_t)D * D);
@@ -262,7 +262,7 @@ int Dit::reserve(int B) {
     const size_t nl = (size_t)B * cfg.n_latents * cfg.channels;
     ws_x = (float*)arena.alloc(M * D * 4, true);
     ws_h = (bf16*)arena.alloc(M * D * 2, true);
-    ws_qk = (bf16*)arena.alloc(M * 2 * D * 2, true);
+    ws_qk = (bf16*)arena.alloc(M * 3 * D * 2, true);       // q | k | v rows of 3*D
     ws_vt = (bf16*)arena.alloc((size_t)B * D * cfg.n_latents * 2, true);
     ws_o = (bf16*)arena.alloc(M * D * 2, true);
     ws_q2 = (bf16*)arena.alloc(M * D * 2, true);
@@ -506,16 +506,30 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
         // ---- x += attn1(norm1(x, t))                                               (:166)
         // (norm1(x) is already in ws_h: produced by the previous block's FF2 epilogue / the prologue)
         (void)m1;
-        GemmArgs qk = gemm_args(ws_h, D, l.w_qk, D, ws_qk, 2 * D, nullptr, M, 2 * D, D);
-        qk.alpha = qscale; qk.alpha_ncols = D;                                      // q columns only
-        RALD_TRY(gemm_nt(qk, EPI_BF16, st));
-        GemmArgs vt = gemm_args(l.w_v, D, ws_h, D, ws_vt, NL, nullptr, D, NL, D);   // V^T = Wv . h^T per sample
-        vt.batch = B; vt.strideB = (int64_t)NL * D; vt.strideC = (int64_t)D * NL;
-        RALD_TRY(gemm_nt(vt, EPI_BF16, st));
+        // one projection for q | k | v (N = 1536); the attention kernel reads V row-major through ds_read_b64_tr_b16, so no
+        // transposed copy of V and no separate V^T GEMM (RALD_ATTN_VROW=0: the two-GEMM form, for A/B runs)
+        static const bool vrow_env = !(getenv("RALD_ATTN_VROW") && atoi(getenv("RALD_ATTN_VROW")) == 0);
+        const bool vrow = vrow_env && NL % 64 == 0;
         AttnArgs a1;
-        a1.Q = ws_qk; a1.ldq = 2 * D; a1.strideQ = (int64_t)NL * 2 * D;
-        a1.K = ws_qk + D; a1.ldk = 2 * D; a1.strideK = (int64_t)NL * 2 * D;
-        a1.Vt = ws_vt; a1.ldvt = NL; a1.strideVt = (int64_t)D * NL;
+        if (vrow) {
+            GemmArgs qkv = gemm_args(ws_h, D, l.w_qk, D, ws_qk, 3 * D, nullptr, M, 3 * D, D);
+            qkv.alpha = qscale; qkv.alpha_ncols = D;                                // q columns only
+            RALD_TRY(gemm_nt(qkv, EPI_BF16, st));
+            a1.Q = ws_qk; a1.ldq = 3 * D; a1.strideQ = (int64_t)NL * 3 * D;
+            a1.K = ws_qk + D; a1.ldk = 3 * D; a1.strideK = (int64_t)NL * 3 * D;
+            a1.Vt = nullptr; a1.ldvt = 0; a1.strideVt = 0;
+            a1.V = ws_qk + 2 * D; a1.ldv = 3 * D; a1.strideV = (int64_t)NL * 3 * D;
+        } else {
+            GemmArgs qk = gemm_args(ws_h, D, l.w_qk, D, ws_qk, 2 * D, nullptr, M, 2 * D, D);
+            qk.alpha = qscale; qk.alpha_ncols = D;
+            RALD_TRY(gemm_nt(qk, EPI_BF16, st));
+            GemmArgs vt = gemm_args(l.w_v, D, ws_h, D, ws_vt, NL, nullptr, D, NL, D);   // V^T = Wv . h^T per sample
+            vt.batch = B; vt.strideB = (int64_t)NL * D; vt.strideC = (int64_t)D * NL;
+            RALD_TRY(gemm_nt(vt, EPI_BF16, st));
+            a1.Q = ws_qk; a1.ldq = 2 * D; a1.strideQ = (int64_t)NL * 2 * D;
+            a1.K = ws_qk + D; a1.ldk = 2 * D; a1.strideK = (int64_t)NL * 2 * D;
+            a1.Vt = ws_vt; a1.ldvt = NL; a1.strideVt = (int64_t)D * NL;
+        }
         a1.O = ws_o; a1.ldo = D; a1.strideO = (int64_t)NL * D;
         a1.nq = NL; a1.nk = NL; a1.k_rows = NL; a1.heads = cfg.n_heads; a1.batch = B; a1.scale = scale; a1.q_prescaled = 1;
         RALD_TRY(attention_d64(a1, st));

@@ -77,6 +77,9 @@ struct AttnArgs {
     const bf16* Q;  int64_t ldq,  strideQ;     // Q [b][i][h*64+d]
     const bf16* K;  int64_t ldk,  strideK;     // K [b][j][h*64+d]
     const bf16* Vt; int64_t ldvt, strideVt;    // Vt[b][h*64+d][j]  (keys contiguous, zero padded to 32)
+    // alternative V operand, row-major like K (V[b][j][h*64+d]): set V and leave Vt null; needs nk % 64 == 0.  Read through
+    // ds_read_b64_tr_b16, so a fused q|k|v projection can feed the kernel without a transposed copy of V.
+    const bf16* V = nullptr; int64_t ldv = 0, strideV = 0;
     bf16* O;        int64_t ldo,  strideO;     // O [b][i][h*64+d]
     int nq, nk, heads, batch;
     int k_rows;                                // rows allocated per batch in K (>= round_up(nk,64): the tail tile reads them)

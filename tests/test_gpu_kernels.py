@@ -133,6 +133,33 @@ def test_attention_exact_one_hot(H):
     assert torch.equal(out.float().cpu()[0], v[0, sel])
 
 
+def test_attention_row_major_v_transposed_lds_read(H):
+    """V row-major like K (a column slice of a fused q|k|v buffer), transposed on the LDS read (ds_read_b64_tr_b16):
+    exact on a one-hot softmax with integer V (pins the lane / element mapping of the transposed read), and against the
+    torch reference on random data, heads interleaved in a [B, N, 3*H*64] buffer."""
+    B, nq, nk, heads = 1, 64, 128, 1
+    q = torch.zeros(B, nq, 64)
+    k = torch.full((B, nk, 64), -16.0)
+    sel = (torch.arange(nq) * 7 + 3) % nk
+    for i in range(nq):
+        q[0, i, i] = 16.0
+        k[0, sel[i], i] = 16.0
+    v = _ints((B, nk, 64), -8, 8, 5)
+    out = H.op_attention_vrow(q.cuda().bfloat16(), k.cuda().bfloat16(), v.cuda().bfloat16(), heads, 1.0)
+    assert torch.equal(out.float().cpu()[0], v[0, sel])
+    B, n, heads = 3, 512, 8
+    HD = heads * 64
+    g = torch.Generator("cpu").manual_seed(9)
+    qkv = torch.randn(B, n, 3 * HD, generator=g).cuda().bfloat16()
+    scale = 1.0 / math.sqrt(64)
+    out = H.op_attention_vrow(qkv[:, :, :HD], qkv[:, :, HD:2 * HD], qkv[:, :, 2 * HD:], heads, scale)
+    ref = _attn_ref(qkv[:, :, :HD], qkv[:, :, HD:2 * HD], qkv[:, :, 2 * HD:], heads, scale)
+    assert rel_l2(out, ref) < 6e-3
+    vt = qkv[:, :, 2 * HD:].transpose(1, 2).contiguous()
+    old = H.op_attention(qkv[:, :, :HD], qkv[:, :, HD:2 * HD], vt, n, heads, scale)
+    assert torch.equal(out, old)                                   # same arithmetic, different operand path
+
+
 @pytest.mark.parametrize("M,K", [(512, 512), (1000, 2048), (32768, 512), (32768, 2048)])
 def test_gemm_residual_with_fused_layernorm(H, M, K):
     """x += A.W^T + bias and the next (Ada)LayerNorm in one kernel: both outputs against fp32 torch,
