@@ -57,7 +57,8 @@ int Ae::create() {
     mk_attn(dec, d, true);
     layers.resize(c.depth);
     for (auto& l : layers) {
-        l.w_qk = B16((size_t)2 * I * d); l.w_v = B16((size_t)I * d); l.w_o = B16((size_t)d * I); l.b_o = F32(d);
+        l.w_qk = B16((size_t)3 * I * d); l.w_v = l.w_qk + (size_t)2 * I * d;     // to_q | to_k | to_v stacked (w_v = alias of rows 2I..3I)
+        l.w_o = B16((size_t)d * I); l.b_o = F32(d);
         l.ng = F32(d); l.nb = F32(d);
         mk_ff(l.ff);
     }
@@ -344,7 +345,7 @@ int Ae::reserve_decode(int B) {
     x_x = (float*)arena.alloc(b * M * d * 4, true);
     x_part = (float*)arena.alloc((size_t)4 * (b * M < 2048 ? b * M : 2048) * 512 * 4, true);
     x_h = (bf16*)arena.alloc(b * M * d * 2, true);
-    x_qk = (bf16*)arena.alloc(b * M * 2 * I * 2, true);
+    x_qk = (bf16*)arena.alloc(b * M * 3 * I * 2, true);       // q | k | v
     x_vt = (bf16*)arena.alloc(b * I * M * 2, true);
     x_o = (bf16*)arena.alloc(b * M * I * 2, true);
     x_g = (bf16*)arena.alloc(b * M * 4 * d * 2, true);
@@ -385,16 +386,27 @@ int Ae::decode_latents(const float* z, int B, void* ctx, hipStream_t st) {
     for (size_t li = 0; li < layers.size(); ++li) {
         const Layer& l = layers[li];
         // x = self_attn(x) + x   (:413); LN(x) is already in x_h (prologue / previous layer's FF2 epilogue)
-        GemmArgs qk = gemm_args(x_h, d, l.w_qk, d, x_qk, 2 * I, nullptr, BM, 2 * I, d);
-        qk.alpha = scale * 1.4426950408889634f; qk.alpha_ncols = I;
-        RALD_TRY(gemm_nt(qk, EPI_BF16, st));
-        GemmArgs vt = gemm_args(l.w_v, d, x_h, d, x_vt, M, nullptr, I, M, d);
-        vt.batch = B; vt.strideB = (int64_t)M * d; vt.strideC = (int64_t)I * M;
-        RALD_TRY(gemm_nt(vt, EPI_BF16, st));
+        // q | k | v in one projection; V stays row-major and is transposed on the attention kernel's LDS read
         AttnArgs a;
-        a.Q = x_qk; a.ldq = 2 * I; a.strideQ = (int64_t)M * 2 * I;
-        a.K = x_qk + I; a.ldk = 2 * I; a.strideK = (int64_t)M * 2 * I;
-        a.Vt = x_vt; a.ldvt = M; a.strideVt = (int64_t)I * M;
+        if (M % 64 == 0) {
+            GemmArgs qkv = gemm_args(x_h, d, l.w_qk, d, x_qk, 3 * I, nullptr, BM, 3 * I, d);
+            qkv.alpha = scale * 1.4426950408889634f; qkv.alpha_ncols = I;
+            RALD_TRY(gemm_nt(qkv, EPI_BF16, st));
+            a.Q = x_qk; a.ldq = 3 * I; a.strideQ = (int64_t)M * 3 * I;
+            a.K = x_qk + I; a.ldk = 3 * I; a.strideK = (int64_t)M * 3 * I;
+            a.Vt = nullptr; a.ldvt = 0; a.strideVt = 0;
+            a.V = x_qk + 2 * I; a.ldv = 3 * I; a.strideV = (int64_t)M * 3 * I;
+        } else {
+            GemmArgs qk = gemm_args(x_h, d, l.w_qk, d, x_qk, 2 * I, nullptr, BM, 2 * I, d);
+            qk.alpha = scale * 1.4426950408889634f; qk.alpha_ncols = I;
+            RALD_TRY(gemm_nt(qk, EPI_BF16, st));
+            GemmArgs vt = gemm_args(l.w_v, d, x_h, d, x_vt, M, nullptr, I, M, d);
+            vt.batch = B; vt.strideB = (int64_t)M * d; vt.strideC = (int64_t)I * M;
+            RALD_TRY(gemm_nt(vt, EPI_BF16, st));
+            a.Q = x_qk; a.ldq = 2 * I; a.strideQ = (int64_t)M * 2 * I;
+            a.K = x_qk + I; a.ldk = 2 * I; a.strideK = (int64_t)M * 2 * I;
+            a.Vt = x_vt; a.ldvt = M; a.strideVt = (int64_t)I * M;
+        }
         a.O = x_o; a.ldo = I; a.strideO = (int64_t)M * I;
         a.nq = M; a.nk = M; a.k_rows = M; a.heads = cfg.heads; a.batch = B; a.scale = scale; a.q_prescaled = 1;
         RALD_TRY(attention_d64(a, st));
