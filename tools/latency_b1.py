@@ -1,6 +1,6 @@
 """Scratch: eval-style batch-1 latencies, eager launches vs hipGraph replay."""
 import sys, time, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rald_amd import models_radar_generation as G, models_ae as A, weights, synth, config
 m = G.kl_d512_m512_l32_d24_edm(configs=config.shipped_generation_config())
 m.load_state_dict(weights.make_state_dict(weights.dit_spec(depth=24), 0)); m = m.cuda()
