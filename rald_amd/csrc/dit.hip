@@ -121,8 +121,8 @@ int Dit::create() {
         l.b_ff2 = F32(D);
         if (c.qkv_dtype >= 1) {
             auto U8 = [&](size_t n) { return (unsigned char*)arena.alloc(n, true); };
-            l.q8_qk = U8((size_t)2 * D * D); l.s8_qk = U8((size_t)2 * D * D / 32);
-            l.q8_v = U8((size_t)D * D);      l.s8_v = U8((size_t)D * D / 32);
+            l.q8_qk = U8((size_t)3 * D * D); l.s8_qk = U8((size_t)3 * D * D / 32);   // q | k | v stacked like the bf16 weights
+            l.q8_v = l.q8_qk + (size_t)2 * D * D; l.s8_v = l.s8_qk + (size_t)2 * D * D / 32;
             l.q8_q2 = U8((size_t)D * D);     l.s8_q2 = U8((size_t)D * D / 32);
             if (c.qkv_dtype >= 2) { l.q8_ff1 = U8((size_t)8 * D * D); l.s8_ff1 = U8((size_t)8 * D * D / 32); RALD_CHECK(l.q8_ff1 && l.s8_ff1, "dit: device allocation failed"); }
             if (c.qkv_dtype == 3) { l.q8_ff2 = U8((size_t)4 * D * D); l.s8_ff2 = U8((size_t)4 * D * D / 32); RALD_CHECK(l.q8_ff2 && l.s8_ff2, "dit: device allocation failed"); }
@@ -238,8 +238,7 @@ int Dit::finalize() {
     for (const auto& k : expected) RALD_CHECK(loaded.count(k), "dit: missing key '" + k + "' (strict load)");
     if (cfg.qkv_dtype >= 1) {                  // MXFP8 copies of the attention projections, from the bf16 weights
         for (auto& l : layers) {
-            RALD_TRY(quantize_mx8(l.w_qk, 1, D, l.q8_qk, D, l.s8_qk, 2 * D, D, nullptr));
-            RALD_TRY(quantize_mx8(l.w_v, 1, D, l.q8_v, D, l.s8_v, D, D, nullptr));
+            RALD_TRY(quantize_mx8(l.w_qk, 1, D, l.q8_qk, D, l.s8_qk, 3 * D, D, nullptr));      // q | k | v (q8_v / s8_v alias its last third)
             RALD_TRY(quantize_mx8(l.w_q2, 1, D, l.q8_q2, D, l.s8_q2, D, D, nullptr));
             if (cfg.qkv_dtype >= 2) RALD_TRY(quantize_mx8(l.w_ff1, 1, D, l.q8_ff1, D, l.s8_ff1, 8 * D, D, nullptr));
             if (cfg.qkv_dtype == 3) RALD_TRY(quantize_mx8(l.w_ff2, 1, 4 * D, l.q8_ff2, 4 * D, l.s8_ff2, D, 4 * D, nullptr));
@@ -446,16 +445,26 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
             const Layer& l = layers[li];
             const float* m2 = mod + (int64_t)(li * 3 + 1) * 2 * D;
             const float* m3 = mod + (int64_t)(li * 3 + 2) * 2 * D;
-            Mx8Args qk = mx(ws_h8, ws_hs, l.q8_qk, l.s8_qk, ws_qk, 2 * D, nullptr, M, 2 * D);
-            qk.g.alpha = qscale; qk.g.alpha_ncols = D;
-            RALD_TRY(gemm_mx8(qk, EPI_BF16, st));
-            Mx8Args vt = mx(l.q8_v, l.s8_v, ws_h8, ws_hs, ws_vt, NL, nullptr, D, NL);    // V^T = Wv . h^T per sample
-            vt.g.batch = B; vt.g.strideB = (int64_t)NL * D; vt.strideSB = (int64_t)NL * D / 32; vt.g.strideC = (int64_t)D * NL;
-            RALD_TRY(gemm_mx8(vt, EPI_BF16, st));
             AttnArgs a1;
-            a1.Q = ws_qk; a1.ldq = 2 * D; a1.strideQ = (int64_t)NL * 2 * D;
-            a1.K = ws_qk + D; a1.ldk = 2 * D; a1.strideK = (int64_t)NL * 2 * D;
-            a1.Vt = ws_vt; a1.ldvt = NL; a1.strideVt = (int64_t)D * NL;
+            if (NL % 64 == 0) {                                                            // fused q|k|v projection, row-major V (see the bf16 path)
+                Mx8Args qkv = mx(ws_h8, ws_hs, l.q8_qk, l.s8_qk, ws_qk, 3 * D, nullptr, M, 3 * D);
+                qkv.g.alpha = qscale; qkv.g.alpha_ncols = D;
+                RALD_TRY(gemm_mx8(qkv, EPI_BF16, st));
+                a1.Q = ws_qk; a1.ldq = 3 * D; a1.strideQ = (int64_t)NL * 3 * D;
+                a1.K = ws_qk + D; a1.ldk = 3 * D; a1.strideK = (int64_t)NL * 3 * D;
+                a1.Vt = nullptr; a1.ldvt = 0; a1.strideVt = 0;
+                a1.V = ws_qk + 2 * D; a1.ldv = 3 * D; a1.strideV = (int64_t)NL * 3 * D;
+            } else {
+                Mx8Args qk = mx(ws_h8, ws_hs, l.q8_qk, l.s8_qk, ws_qk, 2 * D, nullptr, M, 2 * D);
+                qk.g.alpha = qscale; qk.g.alpha_ncols = D;
+                RALD_TRY(gemm_mx8(qk, EPI_BF16, st));
+                Mx8Args vt = mx(l.q8_v, l.s8_v, ws_h8, ws_hs, ws_vt, NL, nullptr, D, NL);    // V^T = Wv . h^T per sample
+                vt.g.batch = B; vt.g.strideB = (int64_t)NL * D; vt.strideSB = (int64_t)NL * D / 32; vt.g.strideC = (int64_t)D * NL;
+                RALD_TRY(gemm_mx8(vt, EPI_BF16, st));
+                a1.Q = ws_qk; a1.ldq = 2 * D; a1.strideQ = (int64_t)NL * 2 * D;
+                a1.K = ws_qk + D; a1.ldk = 2 * D; a1.strideK = (int64_t)NL * 2 * D;
+                a1.Vt = ws_vt; a1.ldvt = NL; a1.strideVt = (int64_t)D * NL;
+            }
             a1.O = ws_o; a1.ldo = D; a1.strideO = (int64_t)NL * D;
             a1.nq = NL; a1.nk = NL; a1.k_rows = NL; a1.heads = cfg.n_heads; a1.batch = B; a1.scale = scale; a1.q_prescaled = 1;
             RALD_TRY(attention_d64(a1, st));
