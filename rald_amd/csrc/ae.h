@@ -30,9 +30,10 @@ struct Ae {
     bf16 *e_feat = nullptr, *e_emb16 = nullptr, *e_embn16 = nullptr, *e_k = nullptr, *e_vt = nullptr, *e_o = nullptr, *e_xq = nullptr,
          *e_h = nullptr, *e_q2 = nullptr, *e_p = nullptr, *e_g = nullptr;
     float *e_emb32 = nullptr, *e_dq = nullptr, *e_x = nullptr, *e_s = nullptr, *e_ml = nullptr;
+    float* e_part = nullptr;   // key-split partials of the mix attention at small batch (attention.hip)
     std::vector<void**> enc_ptrs() {
         return {(void**)&e_feat, (void**)&e_emb16, (void**)&e_embn16, (void**)&e_k, (void**)&e_vt, (void**)&e_o, (void**)&e_xq, (void**)&e_h,
-                (void**)&e_q2, (void**)&e_p, (void**)&e_g, (void**)&e_emb32, (void**)&e_dq, (void**)&e_x, (void**)&e_s, (void**)&e_ml};
+                (void**)&e_q2, (void**)&e_p, (void**)&e_g, (void**)&e_emb32, (void**)&e_dq, (void**)&e_x, (void**)&e_s, (void**)&e_ml, (void**)&e_part};
     }
     // latent-stack workspace
     int dec_batch = 0;

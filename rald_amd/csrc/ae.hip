@@ -265,6 +265,7 @@ int Ae::reserve_encode(int B) {
     e_p = (bf16*)arena.alloc(b * M * Pp * 2, true);
     e_g = (bf16*)arena.alloc(b * M * 4 * d * 2, true);
     e_ml = (float*)arena.alloc(b * M * 2 * L * 4, true);
+    e_part = (float*)arena.alloc((size_t)attention_split_scratch_bytes(16, (int)M, cfg.heads, B), true);
     for (void** p : enc_ptrs()) RALD_CHECK(*p, "ae: encode workspace allocation failed");
     enc_batch = B;
     return 0;
@@ -294,6 +295,8 @@ int Ae::encode(const float* pc, int B, const float* eps, float* mean_o, float* l
     a1.Vt = e_vt; a1.ldvt = Pp; a1.strideVt = (int64_t)I * Pp;
     a1.O = e_o; a1.ldo = I; a1.strideO = (int64_t)M * I;
     a1.nq = M; a1.nk = P; a1.k_rows = Pp; a1.heads = cfg.heads; a1.batch = B; a1.scale = 1.0f / sqrtf((float)cfg.dim_head); a1.q_prescaled = 1;
+    a1.ksplit = attention_pick_ksplit(M, P, cfg.heads, B);            // 512 queries x 10 000 keys: 32 workgroups at B = 1 without it
+    a1.part = e_part;
     RALD_TRY(attention_d64(a1, st));
     GemmArgs o1 = gemm_args(e_o, I, mix.w_o, I, e_dq, d, mix.b_o, BM, d, I);
     RALD_TRY(gemm_nt(o1, EPI_F32, st));

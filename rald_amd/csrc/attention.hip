@@ -40,7 +40,9 @@ __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hf = lane >> 5;
     const int h = blockIdx.y, b = blockIdx.z;
-    int q0 = (blockIdx.x * 4 + wave) * 32;
+    const int ksplit = a.ksplit > 1 ? a.ksplit : 1;
+    const int qblk = blockIdx.x / ksplit, ks = blockIdx.x - qblk * ksplit;
+    int q0 = (qblk * 4 + wave) * 32;
     const bool active = q0 < a.nq;                             // a ragged last workgroup still helps staging
     if (!active) q0 = a.nq - 32;
     const bf16* Q = a.Q + (int64_t)b * a.strideQ + (int64_t)(q0 + r) * a.ldq + h * 64 + 8 * hf;
@@ -94,8 +96,11 @@ __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
     for (int i = 0; i < 16; ++i) negm[i] = 0.f;
     (void)negm;
 
-    const int ntiles = (a.nk + 63) / 64;
-    stage(0, 0);
+    const int ntiles_all = (a.nk + 63) / 64;
+    const int per = (ntiles_all + ksplit - 1) / ksplit;
+    const int t0 = ks * per;
+    const int ntiles = t0 + per < ntiles_all ? t0 + per : ntiles_all;         // this workgroup's key tiles: [t0, ntiles)
+    if (t0 < ntiles) stage(t0 * 64, t0 & 1);
     // one key tile; FIRST (compile-time) peels the tile whose scores are still absolute
     auto tile = [&](const int t, auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
@@ -226,9 +231,27 @@ __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
                 }
             }
     };
-    tile(0, std::true_type{});
-    for (int t = 1; t < ntiles; ++t) tile(t, std::false_type{});
+    if (t0 < ntiles) {
+        tile(t0, std::true_type{});
+        for (int t = t0 + 1; t < ntiles; ++t) tile(t, std::false_type{});
+    }
     l += __shfl_xor(l, 32, 64);
+    if (ksplit > 1) {
+        // partial result of this key range: unnormalised O (fp32), running max in exp2 units and the sum - combined by
+        // attention_combine_kernel.  Layout: part[((ks*batch + b)*heads + h)*nq + q][66] = {O[0..63], m, l}.
+        if (active) {
+            float* P = a.part + ((((int64_t)ks * a.batch + b) * a.heads + h) * a.nq + q0 + r) * 66;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *reinterpret_cast<float2*>(P + 8 * g + 4 * hf) = make_float2(o0[4 * g], o0[4 * g + 1]);
+                *reinterpret_cast<float2*>(P + 8 * g + 4 * hf + 2) = make_float2(o0[4 * g + 2], o0[4 * g + 3]);
+                *reinterpret_cast<float2*>(P + 32 + 8 * g + 4 * hf) = make_float2(o1[4 * g], o1[4 * g + 1]);
+                *reinterpret_cast<float2*>(P + 32 + 8 * g + 4 * hf + 2) = make_float2(o1[4 * g + 2], o1[4 * g + 3]);
+            }
+            if (hf == 0) *reinterpret_cast<float2*>(P + 64) = make_float2(t0 < ntiles ? m * c : -1e30f, l);
+        }
+        return;
+    }
     const float inv = 1.0f / l;
 
     // ---- O out: o{dt}[i] = O^T[d = 32dt + (i&3) + 8(i>>2) + 4hf][query q0+r].  Transpose through a
@@ -256,6 +279,40 @@ __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
 }
 
 
+// O[b][q][h*64 + d] = sum_s 2^(m_s - M) O_s[d] / sum_s 2^(m_s - M) l_s, M = max_s m_s; one wave per (b, h, q), lane = d
+__global__ __launch_bounds__(256) void attention_combine_kernel(const float* __restrict__ part, int ksplit, int batch, int heads, int nq,
+                                                                bf16* __restrict__ O, int64_t ldo, int64_t strideO) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);        // (b*heads + h)*nq + q
+    const int64_t rows = (int64_t)batch * heads * nq;
+    if (row >= rows) return;
+    float M = -1e30f;
+    for (int s = 0; s < ksplit; ++s) M = fmaxf(M, part[(s * rows + row) * 66 + 64]);
+    float acc = 0.f, L = 0.f;
+    for (int s = 0; s < ksplit; ++s) {
+        const float* p = part + (s * rows + row) * 66;
+        const float w = fast_exp2(p[64] - M);
+        acc += w * p[lane];
+        L += w * p[65];
+    }
+    const int q = (int)(row % nq);
+    const int64_t bh = row / nq;
+    const int h = (int)(bh % heads);
+    const int64_t b = bh / heads;
+    O[b * strideO + (int64_t)q * ldo + h * 64 + lane] = (bf16)(acc / L);
+}
+
+// few (query block, head, batch) workgroups and many key tiles: split the keys so that ~256 workgroups run
+int attention_pick_ksplit(int nq, int nk, int heads, int batch) {
+    const int64_t wgs = (int64_t)cdiv(nq, 128) * heads * batch;
+    const int ntiles = cdiv(nk, 64);
+    if (wgs >= 128 || ntiles < 16) return 1;
+    int ks = (int)(256 / wgs);
+    if (ks > ntiles / 4) ks = ntiles / 4;
+    if (ks > 16) ks = 16;
+    return ks < 2 ? 1 : ks;
+}
+
 int attention_d64(const AttnArgs& a, hipStream_t st) {
     RALD_CHECK(a.nq > 0 && a.nk > 0 && a.heads > 0 && a.batch > 0, "attention: empty problem");
     RALD_CHECK(a.nq % 32 == 0, "attention: nq must be a multiple of 32");
@@ -269,13 +326,20 @@ int attention_d64(const AttnArgs& a, hipStream_t st) {
         RALD_CHECK(a.Vt && a.ldvt % 8 == 0 && (uintptr_t)a.Vt % 16 == 0, "attention: Vt must be 16-byte aligned with 16-byte rows");
         RALD_CHECK(a.ldvt >= round_up(a.nk, 64), "attention: Vt rows must be padded (finite values) to a multiple of 64 keys");
     }
-    dim3 grid(cdiv(a.nq, 128), a.heads, a.batch);
+    const int ksplit = a.ksplit > 1 ? a.ksplit : 1;
+    if (ksplit > 1) RALD_CHECK(a.part && ksplit <= 64 && (uintptr_t)a.part % 8 == 0, "attention: key split needs a scratch buffer (attention_split_scratch_bytes)");
+    dim3 grid(cdiv(a.nq, 128) * ksplit, a.heads, a.batch);
     if (a.q_prescaled) {
         if (vrow) hipLaunchKernelGGL((attention_d64_kernel<true, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((attention_d64_kernel<true, false>), grid, dim3(256), 0, st, a);
     } else {
         if (vrow) hipLaunchKernelGGL((attention_d64_kernel<false, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((attention_d64_kernel<false, false>), grid, dim3(256), 0, st, a);
+    }
+    if (ksplit > 1) {
+        const int64_t rows = (int64_t)a.batch * a.heads * a.nq;
+        hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a.part, ksplit, a.batch, a.heads, a.nq, a.O,
+                           a.ldo, a.strideO);
     }
     RALD_HIP(hipGetLastError());
     return 0;

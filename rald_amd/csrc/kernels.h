@@ -80,6 +80,10 @@ struct AttnArgs {
     // alternative V operand, row-major like K (V[b][j][h*64+d]): set V and leave Vt null; needs nk % 64 == 0.  Read through
     // ds_read_b64_tr_b16, so a fused q|k|v projection can feed the kernel without a transposed copy of V.
     const bf16* V = nullptr; int64_t ldv = 0, strideV = 0;
+    // key split (few queries x many keys, e.g. 512 latents x 10 000 points at batch 1): ksplit > 1 workgroups share a query block,
+    // each takes a contiguous range of key tiles and writes unnormalised partials to `part` (attention_split_scratch_bytes),
+    // a second kernel combines them.  0 / 1 = off; attention_pick_ksplit() suggests a value.
+    int ksplit = 1; float* part = nullptr;
     bf16* O;        int64_t ldo,  strideO;     // O [b][i][h*64+d]
     int nq, nk, heads, batch;
     int k_rows;                                // rows allocated per batch in K (>= round_up(nk,64): the tail tile reads them)
@@ -87,6 +91,8 @@ struct AttnArgs {
     int q_prescaled;                           // Q already multiplied by scale*log2(e) (done for free in the producing GEMM's epilogue)
 };
 int attention_d64(const AttnArgs& a, hipStream_t st);
+int attention_pick_ksplit(int nq, int nk, int heads, int batch);
+inline int64_t attention_split_scratch_bytes(int ksplit, int nq, int heads, int batch) { return (int64_t)ksplit * batch * heads * nq * 66 * 4; }
 
 // ---------------------------------------------------------------- small.hip
 enum { ACT_NONE = 0, ACT_SILU = 1 };
