@@ -318,6 +318,13 @@ int rald_op_attention(const void* Q, int64_t ldq, int64_t strideQ, const void* K
                       int32_t nq, int32_t nk, int32_t k_rows, int32_t heads, int32_t batch, float scale, void* stream);
 /* fused residual GEMM + next LayerNorm (N = 512): x[M][512] += A[M][K].W[512][K]^T + bias (fp32, in place);
  * h_bf16 = LayerNorm(x) * (add_one + g[row/rows_per_group*gstride + c]) + b[...] */
+/* rald_op_attention with the keys split over `ksplit` workgroups per query block (few queries x many keys, e.g. 512
+ * latents x 10 000 points at batch 1): partial results go through `scratch` (rald_op_attention_split_scratch_bytes)
+ * and a combine pass.  ksplit <= 0 picks a value from the shape. */
+int64_t rald_op_attention_split_scratch_bytes(int32_t ksplit, int32_t nq, int32_t heads, int32_t batch);
+int rald_op_attention_split(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK, const void* Vt, int64_t ldvt,
+                            int64_t strideVt, void* O, int64_t ldo, int64_t strideO, int32_t nq, int32_t nk, int32_t k_rows, int32_t heads,
+                            int32_t batch, float scale, int32_t ksplit, void* scratch, void* stream);
 /* rald_op_attention with V row-major like K (V[b][j][h*64+d], e.g. a column slice of a fused q|k|v projection): the kernel
  * transposes it on the LDS read (ds_read_b64_tr_b16).  nk % 64 == 0. */
 int rald_op_attention_vrow(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK, const void* V, int64_t ldv,

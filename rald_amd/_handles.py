@@ -235,6 +235,17 @@ def op_attention(Q: torch.Tensor, K: torch.Tensor, Vt: torch.Tensor, nk: int, he
     return O
 
 
+def op_attention_split(Q: torch.Tensor, K: torch.Tensor, Vt: torch.Tensor, nk: int, heads: int, scale: float, ksplit: int) -> torch.Tensor:
+    """op_attention with the keys split over `ksplit` workgroups per query block (+ combine pass)."""
+    Bn, nq, HD = Q.shape
+    O = torch.empty(Bn, nq, HD, device=Q.device, dtype=torch.bfloat16)
+    scratch = torch.empty(max(8, lib().rald_op_attention_split_scratch_bytes(max(ksplit, 16), nq, heads, Bn)), device=Q.device, dtype=torch.uint8)
+    check(lib().rald_op_attention_split(C.c_void_p(_ptr(Q)), Q.stride(1), Q.stride(0), C.c_void_p(_ptr(K)), K.stride(1), K.stride(0),
+                                        C.c_void_p(_ptr(Vt)), Vt.stride(1), Vt.stride(0), C.c_void_p(_ptr(O)), O.stride(1), O.stride(0),
+                                        nq, nk, K.shape[1], heads, Bn, scale, ksplit, C.c_void_p(_ptr(scratch)), C.c_void_p(_stream())))
+    return O
+
+
 def op_attention_vrow(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
     """Q [B,nq,H*64], K / V [B,nk,H*64] (bf16, possibly column slices of one fused buffer) -> O [B,nq,H*64] bf16."""
     Bn, nq, HD = Q.shape

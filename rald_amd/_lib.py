@@ -120,6 +120,9 @@ SIGNATURES = {
     "rald_op_layernorm": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_i64, c_int, c_float, c_float, c_void_p]),
     "rald_op_attention": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64,
                                   c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "rald_op_attention_split_scratch_bytes": (c_i64, [c_int, c_int, c_int, c_int]),
+    "rald_op_attention_split": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64,
+                                        c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
     "rald_op_attention_vrow": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64,
                                        c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "rald_op_gemm_resid_ln": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int,

@@ -371,6 +371,21 @@ int rald_op_attention(const void* Q, int64_t ldq, int64_t strideQ, const void* K
     if (const char* e = getenv("RALD_ATTN_PRESCALED")) a.q_prescaled = atoi(e);   // timing experiments only
     return attention_d64(a, (hipStream_t)stream);
 }
+int64_t rald_op_attention_split_scratch_bytes(int32_t ksplit, int32_t nq, int32_t heads, int32_t batch) {
+    return attention_split_scratch_bytes(ksplit, nq, heads, batch);
+}
+int rald_op_attention_split(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK, const void* Vt, int64_t ldvt,
+                            int64_t strideVt, void* O, int64_t ldo, int64_t strideO, int32_t nq, int32_t nk, int32_t k_rows, int32_t heads,
+                            int32_t batch, float scale, int32_t ksplit, void* scratch, void* stream) {
+    RALD_CHECK(Q && K && Vt && O, "rald_op_attention_split: null pointer");
+    AttnArgs a;
+    a.Q = (const bf16*)Q; a.ldq = ldq; a.strideQ = strideQ; a.K = (const bf16*)K; a.ldk = ldk; a.strideK = strideK;
+    a.Vt = (const bf16*)Vt; a.ldvt = ldvt; a.strideVt = strideVt; a.O = (bf16*)O; a.ldo = ldo; a.strideO = strideO;
+    a.nq = nq; a.nk = nk; a.k_rows = k_rows; a.heads = heads; a.batch = batch; a.scale = scale; a.q_prescaled = 0;
+    a.ksplit = ksplit > 0 ? ksplit : attention_pick_ksplit(nq, nk, heads, batch);
+    a.part = (float*)scratch;
+    return attention_d64(a, (hipStream_t)stream);
+}
 int rald_op_attention_vrow(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK, const void* V, int64_t ldv,
                            int64_t strideV, void* O, int64_t ldo, int64_t strideO, int32_t nq, int32_t nk, int32_t heads, int32_t batch, float scale,
                            void* stream) {

@@ -133,6 +133,27 @@ def test_attention_exact_one_hot(H):
     assert torch.equal(out.float().cpu()[0], v[0, sel])
 
 
+def test_attention_key_split_equals_unsplit(H):
+    """Few queries x many ragged keys (the AE's 512 latents x 10 000 points): key ranges on separate workgroups + combine
+    pass against the single-pass kernel and the torch reference, for several split counts (incl. more splits than tiles)."""
+    B, nq, nk, heads = 1, 128, 1000, 2
+    HD, nkp = heads * 64, 1024
+    g = torch.Generator("cpu").manual_seed(13)
+    q = torch.randn(B, nq, HD, generator=g).cuda().bfloat16()
+    k = torch.full((B, nkp, HD), 7.0).cuda().bfloat16()
+    k[:, :nk] = torch.randn(B, nk, HD, generator=g).cuda().bfloat16()
+    v = torch.randn(B, nk, HD, generator=g).cuda().bfloat16()
+    vt = torch.zeros(B, HD, nkp, device="cuda", dtype=torch.bfloat16)
+    vt[:, :, :nk] = v.transpose(1, 2)
+    scale = 1.0 / math.sqrt(64)
+    ref = _attn_ref(q, k[:, :nk], v, heads, scale)
+    base = H.op_attention(q, k, vt, nk, heads, scale)
+    for ks in (2, 5, 16, 40, 0):
+        out = H.op_attention_split(q, k, vt, nk, heads, scale, ks)
+        assert rel_l2(out, ref) < 6e-3, ks
+        assert rel_l2(out, base) < 4e-3, ks                         # P is rounded to bf16 against a different running max
+
+
 def test_attention_row_major_v_transposed_lds_read(H):
     """V row-major like K (a column slice of a fused q|k|v buffer), transposed on the LDS read (ds_read_b64_tr_b16):
     exact on a one-hot softmax with integer V (pins the lane / element mapping of the transposed read), and against the
