@@ -30,18 +30,56 @@ namespace rald {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// RALD_ATTN_ABLATE (tools/probe/attn_ablate.hip only; 0 in the library): bit 0 no v_exp, bit 1 no running max, bit 2 V fragments read once
+// per tile, bit 3 no PV MFMA, bit 4 K fragments read once per sub-tile - a way to see which unit bounds the kernel.
+#ifndef RALD_ATTN_ABLATE
+#define RALD_ATTN_ABLATE 0
+#endif
+__device__ __forceinline__ float fast_exp2(float x) {
+    if constexpr (RALD_ATTN_ABLATE & 1) return x * 0.5f;
+    else return __builtin_amdgcn_exp2f(x);
+}
 
+#ifndef RALD_ATTN_LAZY
+#define RALD_ATTN_LAZY 8.f
+#endif
+#ifndef RALD_ATTN_PRIO
+#define RALD_ATTN_PRIO 1   // raise the wave priority over the QK^T MFMAs (neutral at 512 keys, +3 % at 2048+)
+#endif
+#ifndef RALD_ATTN_STAGES
+#define RALD_ATTN_STAGES 2
+#endif
+#ifdef RALD_ATTN_WPE
+#define RALD_ATTN_ATTR __attribute__((amdgpu_waves_per_eu(RALD_ATTN_WPE, RALD_ATTN_WPE)))
+#else
+#define RALD_ATTN_ATTR
+#endif
 template <bool PRESCALED, bool VROW>
-__global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) RALD_ATTN_ATTR void attention_d64_kernel(AttnArgs a) {
     constexpr int TILE_BYTES = 64 * 128;                       // 64 rows x 128 B (K: keys x d, Vt: d x keys)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE_BYTES];   // [buf][K | Vt]
+    constexpr int NST = RALD_ATTN_STAGES;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NST * 2 * TILE_BYTES];   // [buf][K | Vt]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hf = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
+    // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs (each with its own L2) in launch order, and all the
+    // workgroups of one (batch, head) stream the same K/V.  Give every (batch, head) to ONE XCD - launch index L -> XCD L & 7,
+    // slot L >> 3 -> (pair slot/nx of that XCD, block slot%nx) - so its K/V crosses the fabric once instead of once per query
+    // block (4x at 512 latents: 268 MB -> 67 MB per launch at batch 64, which was the kernel's bound).
     const int ksplit = a.ksplit > 1 ? a.ksplit : 1;
-    const int qblk = blockIdx.x / ksplit, ks = blockIdx.x - qblk * ksplit;
+    const int nx = ((a.nq + 127) >> 7) * ksplit;
+    const int nbh = a.heads * a.batch;
+    int bh, bx;
+    if ((nbh & 7) == 0) {
+        const int slot = blockIdx.x >> 3;
+        bh = (slot / nx) * 8 + (blockIdx.x & 7);
+        bx = slot % nx;
+    } else {
+        bh = blockIdx.x / nx;
+        bx = blockIdx.x % nx;
+    }
+    const int h = bh % a.heads, b = bh / a.heads;
+    const int qblk = bx / ksplit, ks = bx - qblk * ksplit;
     int q0 = (qblk * 4 + wave) * 32;
     const bool active = q0 < a.nq;                             // a ragged last workgroup still helps staging
     if (!active) q0 = a.nq - 32;
@@ -100,19 +138,24 @@ __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
     const int per = (ntiles_all + ksplit - 1) / ksplit;
     const int t0 = ks * per;
     const int ntiles = t0 + per < ntiles_all ? t0 + per : ntiles_all;         // this workgroup's key tiles: [t0, ntiles)
-    if (t0 < ntiles) stage(t0 * 64, t0 & 1);
+    if (t0 < ntiles) stage(t0 * 64, t0 % NST);
+    if (NST == 3 && t0 + 1 < ntiles) stage((t0 + 1) * 64, (t0 + 1) % NST);
     // one key tile; FIRST (compile-time) peels the tile whose scores are still absolute
     auto tile = [&](const int t, auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
         const int j0 = t * 64;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my pieces of tile t have landed
-        __builtin_amdgcn_s_barrier();                          // ... and everyone's; buffer (t+1)&1 is free
+        if (NST == 3 && t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile t+1's four pieces may still fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of tile t have landed
+        __builtin_amdgcn_s_barrier();                          // ... and everyone's; the buffer of tile t-1 is free
         asm volatile("" ::: "memory");
-        if (t + 1 < ntiles) stage(j0 + 64, (t + 1) & 1);
-        const unsigned char* sK = smem + (t & 1) * 2 * TILE_BYTES;
+        if (t + NST - 1 < ntiles) stage(j0 + 64 * (NST - 1), (t + NST - 1) % NST);
+        const unsigned char* sK = smem + (t % NST) * 2 * TILE_BYTES;
         const unsigned char* sV = sK + TILE_BYTES;
 
         // ---- S^T = K.Q^T for the two 32-key sub-tiles
+#if RALD_ATTN_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
         f32x16 st[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -122,12 +165,16 @@ __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
                 for (int i = 0; i < 16; ++i) st[u][i] = 0.f;
             }
             const int krow = 32 * u + r;
+            bf16x8 kf;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + krow * 128 + (((2 * s + hf) ^ ((krow >> 1) & 7)) << 4));
+                if (!(RALD_ATTN_ABLATE & 16) || s == 0) kf = *reinterpret_cast<const bf16x8*>(sK + krow * 128 + (((2 * s + hf) ^ ((krow >> 1) & 7)) << 4));
                 st[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[u], 0, 0, 0);
             }
         }
+#if RALD_ATTN_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         // st[u][i] = score(key j0 + 32u + (i&3) + 8*(i>>2) + 4*hf, query q0 + r)  [PRESCALED: minus m, exp2 units]
         if (j0 + 64 > a.nk) {                                  // ragged last tile only (wave-uniform)
 #pragma unroll
@@ -137,14 +184,20 @@ __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
                     if (j0 + 32 * u + (i & 3) + 8 * (i >> 2) + 4 * hf >= a.nk) st[u][i] = -1e30f;
         }
         float mx = st[0][0];
+        if constexpr (RALD_ATTN_ABLATE & 2) mx = FIRST ? 8.f : 0.f;
+        else {
 #pragma unroll
-        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, st[0][i]);
+            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, st[0][i]);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[1][i]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[1][i]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        }
         if constexpr (PRESCALED) {
-            // mx is relative to the old max (absolute on the first tile): > 0 means this lane's max moved
-            if (FIRST || __any(mx > 0.f)) {
+            // mx is relative to the reference max m (absolute on the first tile).  m only has to be NEAR the row max - the
+            // softmax is invariant to it and fp32 / bf16 exponents have the room - so it moves only when some lane's scores
+            // exceed it by more than RALD_ATTN_LAZY (exp2 units, p <= 2^LAZY): with an exact running max the branch below was
+            // taken on practically every tile (P(no row of 32 sets a new max) ~ 0), costing 32 O multiplies + 32 subtracts each.
+            if (FIRST || __any(mx > RALD_ATTN_LAZY)) {
                 const float delta = FIRST ? mx : fmaxf(mx, 0.f);
                 if constexpr (FIRST) m = mx;
                 else {
@@ -172,7 +225,7 @@ __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
                 }
             l += ps2[0] + ps2[1];                              // per-half partial; halves summed at the end
         } else {
-            if (__any(mx > m)) {                               // somebody's max moved: rescale what is at the old max
+            if (__any((mx - m) * c > RALD_ATTN_LAZY)) {        // somebody's scores left the reference max far behind: move it
                 const float mn = fmaxf(m, mx);
                 const float alpha = fast_exp2((m - mn) * c);
                 m = mn;
@@ -193,6 +246,8 @@ __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
         }
 
         // ---- O^T += V^T.P^T ; element j of the P fragment <-> key 32u + 16s + 8(j>>2) + 4hf + (j&3)
+        bf16x4 lo_keep[2], hi_keep[2];
+        (void)lo_keep; (void)hi_keep;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -204,7 +259,13 @@ __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
                     bf16x4 lo, hi;
-                    if constexpr (VROW) {
+                    if constexpr ((RALD_ATTN_ABLATE & 4) != 0) {
+                        if (u == 0 && s == 0) {
+                            lo_keep[dt] = *reinterpret_cast<const bf16x4*>(sV + (32 * dt + r) * 128 + 8 * hf);
+                            hi_keep[dt] = *reinterpret_cast<const bf16x4*>(sV + (32 * dt + r) * 128 + 8 * hf + 16);
+                        }
+                        lo = lo_keep[dt]; hi = hi_keep[dt];
+                    } else if constexpr (VROW) {
                         // ds_read_b64_tr_b16: per 16-lane group, lane 4q+p supplies row (key) q, columns 4p..4p+3 of a 4x16 block and
                         // lane i receives column i of the 4 rows.  Group g: d columns 32dt + 16(g&1) + i, keys 32u + 16s + 4(g>>1) + q
                         // (lo) and + 8 (hi) - exactly the element order of the P fragment above.
@@ -226,7 +287,10 @@ __global__ __launch_bounds__(256) void attention_d64_kernel(AttnArgs a) {
                         hi = *reinterpret_cast<const bf16x4*>(vr + (((ch + 1) ^ ((vrow >> 1) & 7)) << 4));
                     }
                     const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o0, 0, 0, 0);
+                    if constexpr ((RALD_ATTN_ABLATE & 8) != 0) {
+                        if (dt == 0) o0[u * 2 + s] += (float)vf[0] * (float)pf[0] + (float)pf[7];
+                        else o1[u * 2 + s] += (float)vf[0] * (float)pf[1] + (float)pf[6];
+                    } else if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o0, 0, 0, 0);
                     else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o1, 0, 0, 0);
                 }
             }
@@ -328,7 +392,8 @@ int attention_d64(const AttnArgs& a, hipStream_t st) {
     }
     const int ksplit = a.ksplit > 1 ? a.ksplit : 1;
     if (ksplit > 1) RALD_CHECK(a.part && ksplit <= 64 && (uintptr_t)a.part % 8 == 0, "attention: key split needs a scratch buffer (attention_split_scratch_bytes)");
-    dim3 grid(cdiv(a.nq, 128) * ksplit, a.heads, a.batch);
+    RALD_CHECK((int64_t)cdiv(a.nq, 128) * ksplit * a.heads * a.batch < (1ll << 31), "attention: too many workgroups");
+    dim3 grid(cdiv(a.nq, 128) * ksplit * a.heads * a.batch);
     if (a.q_prescaled) {
         if (vrow) hipLaunchKernelGGL((attention_d64_kernel<true, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((attention_d64_kernel<true, false>), grid, dim3(256), 0, st, a);
