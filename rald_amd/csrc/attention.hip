@@ -31,7 +31,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
 // RALD_ATTN_ABLATE (tools/probe/attn_ablate.hip only; 0 in the library): bit 0 no v_exp, bit 1 no running max, bit 2 V fragments read once
-// per tile, bit 3 no PV MFMA, bit 4 K fragments read once per sub-tile - a way to see which unit bounds the kernel.
+// per tile, bit 3 no PV MFMA, bit 4 K fragments read once per sub-tile, bit 5 no K/V staging, waits or barriers after the first tile - a way to see which unit bounds the kernel.
 #ifndef RALD_ATTN_ABLATE
 #define RALD_ATTN_ABLATE 0
 #endif
@@ -62,6 +62,9 @@ __global__ __launch_bounds__(256) RALD_ATTN_ATTR void attention_d64_kernel(AttnA
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hf = lane >> 5;
+#if RALD_ATTN_ABLATE & 64
+    const long long clk0 = clock64(), wall0 = wall_clock64();
+#endif
     // XCD-aware placement: workgroups are dealt round-robin to the 8 XCDs (each with its own L2) in launch order, and all the
     // workgroups of one (batch, head) stream the same K/V.  Give every (batch, head) to ONE XCD - launch index L -> XCD L & 7,
     // slot L >> 3 -> (pair slot/nx of that XCD, block slot%nx) - so its K/V crosses the fabric once instead of once per query
@@ -144,11 +147,13 @@ __global__ __launch_bounds__(256) RALD_ATTN_ATTR void attention_d64_kernel(AttnA
     auto tile = [&](const int t, auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
         const int j0 = t * 64;
+        if (!(RALD_ATTN_ABLATE & 32) || FIRST) {
         if (NST == 3 && t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile t+1's four pieces may still fly
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of tile t have landed
         __builtin_amdgcn_s_barrier();                          // ... and everyone's; the buffer of tile t-1 is free
         asm volatile("" ::: "memory");
-        if (t + NST - 1 < ntiles) stage(j0 + 64 * (NST - 1), (t + NST - 1) % NST);
+        }
+        if (!(RALD_ATTN_ABLATE & 32) && t + NST - 1 < ntiles) stage(j0 + 64 * (NST - 1), (t + NST - 1) % NST);
         const unsigned char* sK = smem + (t % NST) * 2 * TILE_BYTES;
         const unsigned char* sV = sK + TILE_BYTES;
 
@@ -300,6 +305,9 @@ __global__ __launch_bounds__(256) RALD_ATTN_ATTR void attention_d64_kernel(AttnA
         for (int t = t0 + 1; t < ntiles; ++t) tile(t, std::false_type{});
     }
     l += __shfl_xor(l, 32, 64);
+#if RALD_ATTN_ABLATE & 64
+    if (threadIdx.x == 0 && blockIdx.x == 1000 && a.part) { a.part[0] = (float)(clock64() - clk0); a.part[1] = (float)(wall_clock64() - wall0); }
+#endif
     if (ksplit > 1) {
         // partial result of this key range: unnormalised O (fp32), running max in exp2 units and the sum - combined by
         // attention_combine_kernel.  Layout: part[((ks*batch + b)*heads + h)*nq + q][66] = {O[0..63], m, l}.

@@ -193,8 +193,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
+#ifdef RALD_GEMM_CLOCK   // tools/probe/gemm_clock.hip: shader clocks vs the 100 MHz wall clock over one workgroup's life
+__device__ long long g_gemm_clk[2];
+#endif
 template <int BM, int BN, int WM, int WN, int NSTAGE, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_glds_kernel(GemmArgs a) {
+#ifdef RALD_GEMM_CLOCK
+    const long long clk0 = clock64(), wall0 = wall_clock64();
+#endif
     constexpr int BK = 64;
     constexpr int WAVES = WM * WN;
     constexpr int MT = BM / (16 * WM);       // m-tiles per wave
@@ -358,6 +364,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_glds_kernel(GemmArgs a) 
     __builtin_amdgcn_s_barrier();             // every wave is done reading the staging buffers: reuse them as patches
     asm volatile("" ::: "memory");
     gemm_epilogue_lds<MT, NT, EPI>(acc, a, m0 + wm * (BM / WM), n0 + wn * (BN / WN), coff, lane, smem + wave * 8704);
+#ifdef RALD_GEMM_CLOCK
+    if (tid == 0 && lin == nt / 2) { g_gemm_clk[0] = clock64() - clk0; g_gemm_clk[1] = wall_clock64() - wall0; }
+#endif
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -154,6 +154,31 @@ def test_attention_key_split_equals_unsplit(H):
         assert rel_l2(out, base) < 4e-3, ks                         # P is rounded to bf16 against a different running max
 
 
+def test_attention_reference_max_moves_lazily(H, monkeypatch):
+    """The running max only moves when a tile's scores exceed it by more than 2^8 (attention.hip, RALD_ATTN_LAZY).  Scores that
+    climb tile after tile - by less than the threshold, by far more, and falling - must still give the exact softmax, in
+    the kernel's own-scale path and in the prescaled-q path (q already times scale*log2 e, what the denoiser feeds it)."""
+    B, nq, nk, heads = 1, 64, 512, 1
+    g = torch.Generator("cpu").manual_seed(21)
+    ramp = torch.tensor([0., 3., 5., 40., 41., 100., 104., 300.]).repeat_interleave(64) + torch.rand(nk, generator=g)
+    k = 0.05 * torch.randn(B, nk, 64, generator=g)
+    k[0, :, 0] = ramp
+    q = 0.05 * torch.randn(B, nq, 64, generator=g)
+    q[0, :, 0] = torch.tensor([1.0, 0.5, 0.02, -1.0]).repeat(16)     # steep, moderate, under the threshold, falling
+    v = torch.randn(B, nk, 64, generator=g)
+    qb, kb, vb = q.cuda().bfloat16(), k.cuda().bfloat16(), v.cuda().bfloat16()
+    vt = vb.transpose(1, 2).contiguous()
+    for prescaled, scale in ((0, 1.0), (1, math.log(2.0))):
+        monkeypatch.setenv("RALD_ATTN_PRESCALED", str(prescaled))
+        out = H.op_attention(qb, kb, vt, nk, heads, scale)
+        ref = _attn_ref(qb, kb, vb, heads, scale)
+        assert torch.isfinite(out.float()).all()
+        assert rel_l2(out, ref) < 6e-3, prescaled
+    monkeypatch.delenv("RALD_ATTN_PRESCALED")
+    out = H.op_attention_vrow(qb, kb, vb, heads, 1.0)
+    assert rel_l2(out, _attn_ref(qb, kb, vb, heads, 1.0)) < 6e-3
+
+
 def test_attention_row_major_v_transposed_lds_read(H):
     """V row-major like K (a column slice of a fused q|k|v buffer), transposed on the LDS read (ds_read_b64_tr_b16):
     exact on a one-hot softmax with integer V (pins the lane / element mapping of the transposed read), and against the

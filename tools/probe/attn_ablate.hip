@@ -22,6 +22,7 @@ int main(int argc, char** argv) {
     a.V = qkv + 2 * D; a.ldv = 3 * D; a.strideV = (int64_t)R * 3 * D; a.Vt = nullptr;
     a.O = o; a.ldo = D; a.strideO = (int64_t)N * D;
     a.nq = N; a.nk = NK; a.heads = H; a.batch = B; a.k_rows = R; a.scale = 0.125f; a.q_prescaled = 1;
+    float* part; hipMalloc(&part, 64); hipMemset(part, 0, 64); a.part = part;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 5; ++i) attention_d64(a, 0);
     hipEventRecord(e0, 0);
@@ -31,6 +32,8 @@ int main(int argc, char** argv) {
     std::vector<unsigned short> ho((size_t)B * N * D);
     hipMemcpy(ho.data(), o, ho.size() * 2, hipMemcpyDeviceToHost);
     double cs = 0; for (size_t i = 0; i < ho.size(); ++i) { unsigned u = (unsigned)ho[i] << 16; float f; memcpy(&f, &u, 4); cs += f * ((i % 7) + 1); }
+    float hp[2]; hipMemcpy(hp, part, 8, hipMemcpyDeviceToHost);
+    if (hp[1] > 0) printf("WG 1000: %.0f shader clocks in %.0f ticks of the 100 MHz clock -> %.2f GHz, %.2f us\n", hp[0], hp[1], hp[0] / hp[1] * 0.1, hp[1] * 0.01);
     printf("stages=%d checksum=%.6e ", RALD_ATTN_STAGES, cs);
     printf("nk=%d ablate=%d  %.2f us / launch  (%.0f TFLOP/s nominal)\n", NK, RALD_ATTN_ABLATE, ms * 1000 / 50, 4.0 * N * NK * 64 * H * B / (ms / 50 * 1e-3) / 1e12);
     return 0;
