@@ -15,6 +15,7 @@
 //      through a 4 KiB LDS table and ONE workgroup barrier (single-pass variance in fp32: 512 terms);
 //   3. x_new and h leave through the wave-private LDS transpose as whole rows (16 B per lane).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
@@ -73,6 +74,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs 
             __builtin_amdgcn_global_load_lds((glb_void*)(gB[p] + kt * 128), (lds_void*)(base + BM * 128 + (wave + WAVES * p) * 1024), 16, 0, 0);
     };
 
+    typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+    const bool nt_io_ = (a.nt_io & 1) != 0;
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -133,12 +136,44 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs 
             }
         }
     } else {
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
+    // The residual x_old rides into the accumulators DURING the main loop: k-step q < 8 loads one eighth of this wave's x
+    // tile (MT*NT/8 float4 per lane) right after the next stage's DMA is issued, and k-step q+1 adds it to the accumulators.
+    // With one 160-KiB workgroup per CU every CU is in the same phase at the same time, so an epilogue that first READS
+    // 67 MB of x leaves the MFMA pipe idle chip-wide while HBM streams, and HBM idle while the MFMAs run; spreading the read
+    // over the k-loop overlaps the two (K = 512 at M = 32768: 47 -> 45 us; the rest of the epilogue is the 100 MB of stores, ~10 us,
+    // and a main loop whose k-steps each wait one HBM latency for the A panel at prefetch distance 1).
+    constexpr int XP = MT * NT / 8;                                   // float4 pieces per k-step
+    static_assert(MT * NT % 8 == 0, "x pieces per k-step");
+    nt_f32x4 xt[XP];
+    const int mb_ = m0 + wm * (BM / WM), nb_ = wn * (BN / WN);
+    auto x_load = [&](auto QC) {
+        constexpr int q = decltype(QC)::value;
+#pragma unroll
+        for (int e = 0; e < XP; ++e) {
+            constexpr int dummy = 0; (void)dummy;
+            const int idx = q * XP + e, i = idx / NT, j = idx % NT;
+            int m = mb_ + i * 16 + fr;
+            m = m < a.M ? m : a.M - 1;
+            const nt_f32x4* px = reinterpret_cast<const nt_f32x4*>(a.x + (int64_t)m * BN + nb_ + j * 16 + 4 * fq);
+            xt[e] = nt_io_ ? __builtin_nontemporal_load(px) : *px;
+        }
+    };
+    auto x_add = [&](auto QC) {
+        constexpr int q = decltype(QC)::value;
+#pragma unroll
+        for (int e = 0; e < XP; ++e) {
+            const int idx = q * XP + e, i = idx / NT, j = idx % NT;
+            acc[i][j][0] += xt[e][0]; acc[i][j][1] += xt[e][1]; acc[i][j][2] += xt[e][2]; acc[i][j][3] += xt[e][3];
+        }
+    };
+    auto kstep = [&](int kt, auto QC) {
+        constexpr int q = decltype(QC)::value;                        // 0..7: x piece of this k-step; 8: add the last piece; 9: none
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        if constexpr (q >= 1 && q <= 8) x_add(std::integral_constant<int, q - 1>{});
+        if constexpr (q <= 7) x_load(QC);
         const bf16x8* sA = reinterpret_cast<const bf16x8*>(smem + (kt & 1) * STAGE_BYTES);
         const bf16x8* sB = sA + BM * 8;
 #pragma unroll
@@ -161,10 +196,36 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs 
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
+    };
+    stage(0, 0);
+    if (nk >= 9) {                                                    // K >= 576: pieces over the first eight k-steps
+        kstep(0, std::integral_constant<int, 0>{}); kstep(1, std::integral_constant<int, 1>{});
+        kstep(2, std::integral_constant<int, 2>{}); kstep(3, std::integral_constant<int, 3>{});
+        kstep(4, std::integral_constant<int, 4>{}); kstep(5, std::integral_constant<int, 5>{});
+        kstep(6, std::integral_constant<int, 6>{}); kstep(7, std::integral_constant<int, 7>{});
+        kstep(8, std::integral_constant<int, 8>{});
+        for (int kt = 9; kt < nk; ++kt) kstep(kt, std::integral_constant<int, 9>{});
+    } else if (nk == 8) {                                             // K = 512: the last piece is added after the loop
+        kstep(0, std::integral_constant<int, 0>{}); kstep(1, std::integral_constant<int, 1>{});
+        kstep(2, std::integral_constant<int, 2>{}); kstep(3, std::integral_constant<int, 3>{});
+        kstep(4, std::integral_constant<int, 4>{}); kstep(5, std::integral_constant<int, 5>{});
+        kstep(6, std::integral_constant<int, 6>{}); kstep(7, std::integral_constant<int, 7>{});
+        x_add(std::integral_constant<int, 7>{});
+    } else {                                                          // short K: all of x after the loop
+        for (int kt = 0; kt < nk; ++kt) kstep(kt, std::integral_constant<int, 9>{});
+        x_load(std::integral_constant<int, 0>{}); x_add(std::integral_constant<int, 0>{});
+        x_load(std::integral_constant<int, 1>{}); x_add(std::integral_constant<int, 1>{});
+        x_load(std::integral_constant<int, 2>{}); x_add(std::integral_constant<int, 2>{});
+        x_load(std::integral_constant<int, 3>{}); x_add(std::integral_constant<int, 3>{});
+        x_load(std::integral_constant<int, 4>{}); x_add(std::integral_constant<int, 4>{});
+        x_load(std::integral_constant<int, 5>{}); x_add(std::integral_constant<int, 5>{});
+        x_load(std::integral_constant<int, 6>{}); x_add(std::integral_constant<int, 6>{});
+        x_load(std::integral_constant<int, 7>{}); x_add(std::integral_constant<int, 7>{});
     }
     }
 
-    const bool nt_io = a.nt_io != 0;
+    const bool nt_io = (a.nt_io & 1) != 0;
+    const bool skip_x = (a.nt_io & 2) != 0, skip_h = (a.nt_io & 4) != 0;   // RALD_NT_STORE bits 1 / 2: timing ablations only
     // ---- 1. v = acc + bias + x_old (accumulator layout), row partial sums -------------------------
     const int mb = m0 + wm * (BM / WM);
     const int nb = wn * (BN / WN);
@@ -178,12 +239,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs 
         for (int j = 0; j < NT; ++j) {
             const int n = nb + j * 16 + 4 * fq;
             const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
-            // the residual stream, the new x and h are touched once per call: non-temporal, so they do not push the
-            // weight panel (the only re-read operand) out of L2
-            typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
-            const nt_f32x4 xv = nt_io ? __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(a.x + (int64_t)m * BN + n))
-                                      : *reinterpret_cast<const nt_f32x4*>(a.x + (int64_t)m * BN + n);
-            const float4 xo = make_float4(xv[0], xv[1], xv[2], xv[3]);
+            // (bf16 operands: x_old is already in the accumulators, see the main loop)
+            float4 xo = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (MX) {
+                const nt_f32x4 xv = nt_io ? __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(a.x + (int64_t)m * BN + n))
+                                          : *reinterpret_cast<const nt_f32x4*>(a.x + (int64_t)m * BN + n);
+                xo = make_float4(xv[0], xv[1], xv[2], xv[3]);
+            }
             f32x4 v = acc[i][j];
             v[0] += b.x + xo.x; v[1] += b.y + xo.y; v[2] += b.z + xo.z; v[3] += b.w + xo.w;
             acc[i][j] = v;
@@ -232,7 +294,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs 
                 const int r = r0 + lane / LPR, pc = lane % LPR;
                 const int m = mb + i * 16 + r;
                 const uint4 v = *reinterpret_cast<const uint4*>(patch + r * STRIDE_F + pc * 16);
-                if (m < a.M) {
+                if (m < a.M && !skip_x) {
                     typedef unsigned int nt_u32x4 __attribute__((ext_vector_type(4)));
                     if (nt_io) __builtin_nontemporal_store(nt_u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_u32x4*>(a.x + (int64_t)m * BN + nb + pc * 4));
                     else *reinterpret_cast<uint4*>(a.x + (int64_t)m * BN + nb + pc * 4) = v;
@@ -276,7 +338,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs 
                         *reinterpret_cast<uint2*>(a.h8 + mc * BN + col) = *reinterpret_cast<const uint2*>(q8);
                         if ((pc & 3) == 0) a.hs[mc * (BN / 32) + col / 32] = sc;
                     }
-                } else if (mm < a.M) {
+                } else if (mm < a.M && !skip_h) {
                     typedef unsigned int nt_u32x4 __attribute__((ext_vector_type(4)));
                     if (nt_io) __builtin_nontemporal_store(nt_u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_u32x4*>(a.h + (int64_t)mm * BN + nb + pc * 8));
                     else *reinterpret_cast<uint4*>(a.h + (int64_t)mm * BN + nb + pc * 8) = v;
