@@ -346,7 +346,7 @@ int Ae::reserve_decode(int B) {
     for (void** p : dec_ptrs()) if (*p) { arena.release(*p); *p = nullptr; }
     const size_t M = cfg.num_latents, b = B;
     x_x = (float*)arena.alloc(b * M * d * 4, true);
-    x_part = (float*)arena.alloc((size_t)4 * (b * M < 2048 ? b * M : 2048) * 512 * 4, true);
+    x_part = (float*)arena.alloc((size_t)4 * (b * M < splitk_max_rows() ? b * M : splitk_max_rows()) * 512 * 4, true);
     x_h = (bf16*)arena.alloc(b * M * d * 2, true);
     x_qk = (bf16*)arena.alloc(b * M * 3 * I * 2, true);       // q | k | v
     x_vt = (bf16*)arena.alloc(b * I * M * 2, true);

@@ -266,7 +266,7 @@ int Dit::reserve(int B) {
     ws_o = (bf16*)arena.alloc(M * D * 2, true);
     ws_q2 = (bf16*)arena.alloc(M * D * 2, true);
     ws_g = (bf16*)arena.alloc(M * 4 * D * 2, true);
-    ws_part = (float*)arena.alloc((size_t)4 * (M < 2048 ? M : 2048) * 512 * 4, true);
+    ws_part = (float*)arena.alloc((size_t)4 * (M < splitk_max_rows() ? M : splitk_max_rows()) * 512 * 4, true);
     ws_tok = (bf16*)arena.alloc((size_t)B * cfg.n_cond_tokens * cfg.context_dim * 2, true);
     ws_xcur = (float*)arena.alloc(nl * 4, true);
     ws_xeul = (float*)arena.alloc(nl * 4, true);

@@ -455,6 +455,9 @@ static int gemm_nt_impl(const GemmArgs& a, int epi, hipStream_t st) {
         // small-M (batch-1) regime: too few tiles to hide memory latency behind other workgroups, so put
         // (up to) the whole K extent in flight at once: 64x64 tiles, 8-stage LDS-DMA ring (128 KB).
         const int64_t wg64 = (int64_t)cdiv(a.M, 64) * cdiv(a.N, 64) * nbatch;
+        static const int mid = getenv("RALD_GEMM_MID") ? atoi(getenv("RALD_GEMM_MID")) : 0;   // A/B: 1 = LDS-DMA 128x128 from 96 tiles up, 2 = LDS-DMA 64x64 ring always
+        if (mid == 1 && wg128 >= 96) return launch_glds<128, 128, 2, 2, 2>(a, epi, st);
+        if (mid == 2) return launch_glds<64, 64, 2, 2, 8>(a, epi, st);
         if (impl == 0 || wg64 > 256) return launch_tile<64, 64>(a, epi, st);   // more than one tile per CU: 5 small workgroups/CU hide latency
         return launch_glds<64, 64, 2, 2, 8>(a, epi, st);
     }

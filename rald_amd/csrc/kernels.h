@@ -1,5 +1,7 @@
 // Internal launch interface of the kernel files (not part of the C-ABI; include/rald_hip.h is).
 #pragma once
+#include <cstdlib>
+
 #include "common.h"
 
 namespace rald {
@@ -153,7 +155,11 @@ int quantize_mx8(const void* in, int in_is_bf16, int64_t ld_in, unsigned char* q
 // small-M split-K residual GEMM + (optional) LayerNorm: see norm.hip.  splitk_for() = 0 when it does not pay.
 int resid_splitk_ln(const bf16* A, int64_t lda, const bf16* W, int64_t ldw, const float* bias, float* x, bf16* h, const float* g, const float* b,
                     int64_t gstride, int rows_per_group, float add_one, float eps, int M, int K, int splits, float* scratch, hipStream_t st);
-inline int splitk_for(int M, int K) { return (K >= 2048 && M <= 2048) ? 4 : 0; }   // [M,512] outputs: < 512 tiles of 64x64
+inline int splitk_max_rows() {                      // RALD_SPLITK_MAXM: A/B switch for the row count up to which split-K pays
+    static const int v = getenv("RALD_SPLITK_MAXM") ? atoi(getenv("RALD_SPLITK_MAXM")) : 4096;
+    return v;
+}
+inline int splitk_for(int M, int K) { return (K >= 2048 && M <= splitk_max_rows()) ? 4 : 0; }   // [M,512] outputs: few 128x128 tiles
 int layernorm_mod_mx8(const float* x, unsigned char* q, unsigned char* scales, int64_t rows, int D, const float* gam, const float* bet,
                       int64_t gstride, int rows_per_group, float add_one, float eps, hipStream_t st);
 
