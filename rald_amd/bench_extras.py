@@ -33,6 +33,10 @@ def run(dit_handle) -> dict:
         out.update(bench_ae.run())
     except ImportError:
         pass
+    try:
+        out.update(_two_streams(dit_handle))
+    except Exception as e:
+        out["two_streams_error"] = repr(e)
     for name, fn in (("fp8", _fp8_mode), ("train", _train_step)):
         try:
             out.update(fn())
@@ -46,6 +50,29 @@ def _denoiser(depth=24):
     m = G.LatentArrayTransformer(in_channels=32, t_channels=256, n_heads=8, d_head=64, depth=depth)
     m.load_state_dict(weights.make_state_dict(weights.dit_spec(depth=depth, with_radar=False, prefix=""), 0))
     return m.cuda()
+
+
+def _two_streams(h0, B=64) -> dict:
+    """Two independent batches of B on two HIP streams (two handles: one stream at a time per handle).  Every kernel of one
+    launch runs the same phase on all CUs at once (MFMA loop, then the HBM-heavy epilogue); a second stream desynchronises
+    them.  Reported beside the headline, which stays one batch of 64 on one stream."""
+    m1 = _denoiser()
+    h1 = m1._handle(512, 64)
+    h1.set_sigmas([1.0])
+    hs = (h0, h1)
+    h0.set_sigmas([1.0])
+    x = synth.latents(range(B)).cuda()
+    cond = synth.cond_tokens(B).cuda()
+    caches = [h.encode_cond_tokens(cond) for h in hs]
+    streams = [torch.cuda.Stream() for _ in hs]
+    torch.cuda.synchronize()
+
+    def both():
+        for h, c, st in zip(hs, caches, streams):
+            with torch.cuda.stream(st):
+                h.denoise(x, c, 0)
+    dt = _time(both, reps=10, warm=3)
+    return {"two_streams_B64x2_nfe_ms": dt * 1e3, "two_streams_B64x2_sample_nfe_per_s": 2 * B / dt}
 
 
 def _fp8_mode(B=64) -> dict:
