@@ -37,7 +37,7 @@ def run(dit_handle) -> dict:
         out.update(_two_streams(dit_handle))
     except Exception as e:
         out["two_streams_error"] = repr(e)
-    for name, fn in (("fp8", _fp8_mode), ("train", _train_step)):
+    for name, fn in (("streams", _sampler_streams), ("fp8", _fp8_mode), ("train", _train_step)):
         try:
             out.update(fn())
         except Exception as e:          # secondary numbers never invalidate the headline line
@@ -73,6 +73,23 @@ def _two_streams(h0, B=64) -> dict:
                 h.denoise(x, c, 0)
     dt = _time(both, reps=10, warm=3)
     return {"two_streams_B64x2_nfe_ms": dt * 1e3, "two_streams_B64x2_sample_nfe_per_s": 2 * B / dt}
+
+
+def _sampler_streams() -> dict:
+    """18-step sampler, radar cube -> latents (condition encode included): B = 1 frames one after the other (the reference's
+    eval loop) against the same frames on concurrent streams (EDMPrecond.sample_concurrent), and two batches of 8."""
+    from . import config, models_radar_generation as G, weights
+    m = G.EDMPrecond(n_latents=512, channels=32, depth=24, configs=config.shipped_generation_config())
+    m.load_state_dict(weights.make_state_dict(weights.dit_spec(depth=24), 0), strict=True)
+    m = m.cuda()
+    out = {}
+    for B, n in ((1, 4), (8, 2)):
+        cubes = [synth.radar_cube(B).cuda() for _ in range(n)]
+        seq = _time(lambda: [m.sample(cond=c, cond_type="radar") for c in cubes], reps=2, warm=1)
+        con = _time(lambda: m.sample_concurrent(cubes, None, cond_type="radar"), reps=2, warm=1)
+        out[f"sample18_B{B}x{n}_sequential_ms"] = seq * 1e3
+        out[f"sample18_B{B}x{n}_concurrent_ms"] = con * 1e3
+    return out
 
 
 def _fp8_mode(B=64) -> dict:

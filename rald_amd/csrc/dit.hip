@@ -21,7 +21,12 @@ void* DeviceArena::alloc(size_t bytes, bool zero) {
     void* p = nullptr;
     if (bytes == 0) bytes = 16;
     if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
-    if (zero) (void)hipMemset(p, 0, bytes);
+    if (zero) {
+        // the memset runs on the null stream, which callers' non-blocking streams (torch side streams) do not wait for:
+        // finish it before anyone can launch work that writes this buffer
+        (void)hipMemset(p, 0, bytes);
+        (void)hipStreamSynchronize(nullptr);
+    }
     ptrs.push_back(p);
     return p;
 }

@@ -63,12 +63,13 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* __restrict__ 
     o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
 }
 
-// GroupNorm statistics (32 groups): stats[b][g] = {sum, sumsq} in double via atomics; x [B][S][C] fp32.
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int S, int C,
+// GroupNorm statistics (32 groups), x [B][S][C] fp32 -> stats[b][g] = {sum, sumsq} in double.  Deterministic (no atomics: the
+// radar condition - and with it every sample drawn from it - is bit-reproducible run to run): each block reduces its
+// voxels in a fixed order and writes one partial per group, gn_finish_kernel adds the partials in block order.
+// part[b][blk][g] = {sum, sumsq}, blk < gridDim.x.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, double* __restrict__ part, int S, int C,
                                                        int vox_per_block) {
-    __shared__ float ssum[32], ssq[32];
-    if (threadIdx.x < 32) { ssum[threadIdx.x] = 0.f; ssq[threadIdx.x] = 0.f; }
-    __syncthreads();
+    __shared__ float4 sp[256];
     const int b = blockIdx.y;
     const int quads = C / 4;                               // float4 pieces per voxel
     const int q = threadIdx.x % quads;
@@ -81,16 +82,29 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
         s0 += t.x + t.y; q0 += t.x * t.x + t.y * t.y;
         s1 += t.z + t.w; q1 += t.z * t.z + t.w * t.w;
     }
-    const int cpg = C / 32;
-    const int g0 = (4 * q) / cpg, g1 = (4 * q + 2) / cpg;
-    atomicAdd(&ssum[g0], s0); atomicAdd(&ssq[g0], q0);
-    atomicAdd(&ssum[g1], s1); atomicAdd(&ssq[g1], q1);
+    sp[threadIdx.x] = make_float4(s0, q0, s1, q1);
     __syncthreads();
     if (threadIdx.x < 32) {
-        atomicAdd(&stats[((int64_t)b * 32 + threadIdx.x) * 2 + 0], (double)ssum[threadIdx.x]);
-        atomicAdd(&stats[((int64_t)b * 32 + threadIdx.x) * 2 + 1], (double)ssq[threadIdx.x]);
+        const int g = threadIdx.x, cpg = C / 32;
+        double su = 0.0, sq = 0.0;
+        for (int t = 0; t < 256; ++t) {                    // fixed order over the block's threads
+            const int tq = t % quads;
+            const float4 p = sp[t];
+            if ((4 * tq) / cpg == g) { su += (double)p.x; sq += (double)p.y; }
+            if ((4 * tq + 2) / cpg == g) { su += (double)p.z; sq += (double)p.w; }
+        }
+        double* o = part + (((int64_t)b * gridDim.x + blockIdx.x) * 32 + g) * 2;
+        o[0] = su; o[1] = sq;
     }
 }
+__global__ __launch_bounds__(64) void gn_finish_kernel(const double* __restrict__ part, double* __restrict__ stats, int nblk) {
+    const int b = blockIdx.x, g = threadIdx.x >> 1, w = threadIdx.x & 1;
+    double acc = 0.0;
+    for (int k = 0; k < nblk; ++k) acc += part[(((int64_t)b * nblk + k) * 32 + g) * 2 + w];
+    stats[((int64_t)b * 32 + g) * 2 + w] = acc;
+}
+constexpr int GN_VPB = 2048;                               // voxels per statistics block
+static inline int gn_blocks(int S) { return (S + GN_VPB - 1) / GN_VPB; }
 
 // y_bf16 = act(GroupNorm(x)) with per-channel affine; act = swish (x*sigmoid(x), :5-7) or identity.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats,
@@ -292,6 +306,7 @@ struct RadarEncoder::Impl {
     float *f0 = nullptr, *f1 = nullptr, *f2 = nullptr, *z = nullptr, *tok = nullptr, *sbuf = nullptr;
     bf16 *n16 = nullptr, *q16 = nullptr, *k16 = nullptr, *vt16 = nullptr, *p16 = nullptr, *o16 = nullptr;
     double* stats = nullptr;
+    int gn_part_blocks = 0;
     int tok_batch = 0;
 
     void add(const std::string& name, Kind k, int cout, int cin) { tensors[name] = Tensor{k, cout, cin}; }
@@ -439,7 +454,8 @@ int RadarEncoder::Impl::ensure_ws(int nsub) {
     f1 = (float*)arena->alloc(act * 4, true);
     f2 = (float*)arena->alloc(act * 4, true);
     n16 = (bf16*)arena->alloc(act * 2, true);
-    stats = (double*)arena->alloc((size_t)nsub * 32 * 2 * 8, true);
+    gn_part_blocks = gn_blocks((int)vox);
+    stats = (double*)arena->alloc((size_t)nsub * 64 * (1 + gn_part_blocks) * 8, true);   // final {sum, sumsq} + per-block partials
     q16 = (bf16*)arena->alloc((size_t)nsub * ntok * cl * 2, true);
     k16 = (bf16*)arena->alloc((size_t)nsub * ntok * cl * 2, true);
     vt16 = (bf16*)arena->alloc((size_t)nsub * cl * ntok * 2, true);
@@ -452,9 +468,10 @@ int RadarEncoder::Impl::ensure_ws(int nsub) {
 }
 
 int RadarEncoder::Impl::gn(const float* x, const std::string& name, bf16* y, int B, int S, int C, bool swish, hipStream_t st) {
-    RALD_HIP(hipMemsetAsync(stats, 0, (size_t)B * 32 * 2 * 8, st));
-    const int vpb = 2048;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(cdiv(S, vpb), B), dim3(256), 0, st, x, stats, S, C, vpb);
+    RALD_CHECK(gn_blocks(S) <= gn_part_blocks, "radar encoder: GroupNorm partial buffer too small");
+    double* part = stats + (size_t)B * 64;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(gn_blocks(S), B), dim3(256), 0, st, x, part, S, C, GN_VPB);
+    hipLaunchKernelGGL(gn_finish_kernel, dim3(B), dim3(64), 0, st, part, stats, gn_blocks(S));
     const int64_t quads = (int64_t)S * C / 4;
     const int blocks = (int)((quads + 255) / 256 < 1024 ? (quads + 255) / 256 : 1024);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, B), dim3(256), 0, st, x, stats, P<float>(name + ".weight"), P<float>(name + ".bias"), y,
@@ -617,9 +634,9 @@ int groupnorm_fwd(const float* x, const float* gamma, const float* beta, bf16* y
                   hipStream_t st) {
     RALD_CHECK(x && gamma && beta && y && stats, "groupnorm: null pointer");
     RALD_CHECK(B > 0 && S > 0 && C % 64 == 0 && 256 % (C / 4) == 0, "groupnorm: channel count must be 64, 128 or 256");
-    RALD_HIP(hipMemsetAsync(stats, 0, (size_t)B * 32 * 2 * 8, st));
-    const int vpb = 2048;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(cdiv(S, vpb), B), dim3(256), 0, st, x, stats, S, C, vpb);
+    double* part = stats + (size_t)B * 64;                 // caller contract: B*64*(1 + ceil(S/2048)) doubles
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(gn_blocks(S), B), dim3(256), 0, st, x, part, S, C, GN_VPB);
+    hipLaunchKernelGGL(gn_finish_kernel, dim3(B), dim3(64), 0, st, part, stats, gn_blocks(S));
     const int64_t quads = (int64_t)S * C / 4;
     const int blocks = (int)((quads + 255) / 256 < 1024 ? (quads + 255) / 256 : 1024);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, B), dim3(256), 0, st, x, stats, gamma, beta, y, S, C, 1e-6f, swish ? 1 : 0);

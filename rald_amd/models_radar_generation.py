@@ -274,6 +274,53 @@ class EDMPrecond(_HipBacked):
         _, cache = self._cond(cond)
         return h.sample(latents, cache, num_steps, float(sigma_min), float(sigma_max), float(rho))
 
+    def _replica(self, i: int) -> DitHandle:
+        """i-th independent C handle over the same parameters (0 = the module's own): a handle runs one stream at a time."""
+        if i == 0:
+            return self._handle()
+        fp = (self._state_fingerprint(), self.qkv_dtype)
+        reps = self.__dict__.setdefault("_replicas", {})
+        if i not in reps or reps[i][1] != fp:
+            h = DitHandle(self._config())
+            h.load(self.state_dict().items())
+            reps[i] = (h, fp)
+        return reps[i][0]
+
+    @torch.no_grad()
+    def sample_concurrent(self, conds, batch_seeds=None, cond_type=None, num_steps=18):
+        """`[self.sample(c, s, cond_type) for c, s in zip(conds, batch_seeds)]` - same values, bit for bit - with every
+        condition batch on its own HIP stream and handle replica.  Not a reference API: the reference's evaluate loop
+        (engine_generation.py:186-232) samples its batches one after the other.  All kernels of one launch run the same
+        phase on every CU at once (MFMA loop, then the HBM-heavy epilogue) and small batches leave most CUs idle; independent
+        streams fill both gaps (two batches of 64: +6 % sample.NFE/s)."""
+        if cond_type != 'radar':
+            raise NotImplementedError("cond_type must be 'radar'")
+        conds = list(conds)
+        seeds = list(batch_seeds) if batch_seeds is not None else [None] * len(conds)
+        if len(seeds) != len(conds):
+            raise ValueError("one seed tensor (or None) per condition batch")
+        cur = torch.cuda.current_stream()
+        streams = self.__dict__.setdefault("_streams", [])
+        while len(streams) < len(conds):
+            streams.append(torch.cuda.Stream())
+        outs = []
+        for i, (cond, sd) in enumerate(zip(conds, seeds)):
+            if sd is None:
+                sd = torch.arange(cond.shape[0])
+            rnd = StackedRandomGenerator(cond.device, sd)
+            latents = rnd.randn([cond.shape[0], self.n_latents, self.channels])
+            h = self._replica(i)
+            streams[i].wait_stream(cur)
+            with torch.cuda.stream(streams[i]):
+                _, cache = h.encode_cond(cond, want_tokens=False)
+                out = h.sample(latents, cache, num_steps, float(max(0.002, self.sigma_min)), float(min(80, self.sigma_max)), 7.0)
+            latents.record_stream(streams[i])          # allocated on the caller's stream, consumed on the side stream
+            out.record_stream(cur)                     # ... and the other way round
+            outs.append(out)
+        for st in streams[:len(conds)]:
+            cur.wait_stream(st)
+        return outs
+
     @torch.no_grad()
     def sample(self, cond, batch_seeds=None, cond_type=None):
         if cond is not None:
