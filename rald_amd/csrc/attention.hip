@@ -73,7 +73,11 @@ __global__ __launch_bounds__(256) RALD_ATTN_ATTR void attention_d64_kernel(AttnA
     const int nx = ((a.nq + 127) >> 7) * ksplit;
     const int nbh = a.heads * a.batch;
     int bh, bx;
+#ifdef RALD_ATTN_PLAIN_GRID   // probe builds only: the launch-order mapping this kernel had before (PMC before/after in profiles/pmc)
+    if (false) {
+#else
     if ((nbh & 7) == 0) {
+#endif
         const int slot = blockIdx.x >> 3;
         bh = (slot / nx) * 8 + (blockIdx.x & 7);
         bx = slot % nx;
