@@ -420,6 +420,8 @@ int gemm_nt(const GemmArgs& a0, int epi, hipStream_t st) {
     static const int nt_store = getenv("RALD_NT_STORE") ? atoi(getenv("RALD_NT_STORE")) : 1;
     GemmArgs a = a0;
     if (nt_store) a.ablate |= 64;
+    static const int diag = getenv("RALD_GEMM_ABLATE") ? atoi(getenv("RALD_GEMM_ABLATE")) : 0;   // diagnostics (PMC runs): OR-ed into GemmArgs::ablate
+    a.ablate |= diag;
     return gemm_nt_impl(a, epi, st);
 }
 static int gemm_nt_impl(const GemmArgs& a, int epi, hipStream_t st) {

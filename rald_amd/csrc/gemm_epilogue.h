@@ -94,7 +94,12 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[MT][NT], const Ge
                     bf16* C = reinterpret_cast<bf16*>(a.C) + coff + (int64_t)m * a.ldc + c;
                     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                     if (c + 8 <= ncols) {
-                        if (a.ablate & 64) __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(C));
+                        // streamed output: system-scope, non-temporal stores write through L2 without allocating.  With plain
+                        // stores - and, inside the NFE, with the compiler's `nt`-only non-temporal store as well - the output
+                        // lines displace the weight / activation panels: FETCH_SIZE of the FF1 GEMM in situ 193 MB per launch
+                        // against 80 MB with this policy (= with no stores at all; profiles/traffic.json)
+                        const u32x4 vv = u32x4{v.x, v.y, v.z, v.w};
+                        if (a.ablate & 64) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(C), "v"(vv) : "memory");
                         else *reinterpret_cast<uint4*>(C) = v;
                     } else *reinterpret_cast<uint2*>(C) = make_uint2(v.x, v.y);   // N % 8 == 4 tail
                 }
