@@ -278,7 +278,7 @@ int rald_op_conv3d(const void* in_bf16, const void* w_packed_bf16, const float* 
 /* W [Cout][Cin][27] f32 (the parameter) -> packed bf16: dgrad = 0: [Cout][27][pad_to >= Cin]; dgrad = 1: the flipped,
  * transposed weights [Cin][27][pad_to >= Cout] that make rald_op_conv3d map dY to dX */
 int rald_op_conv_pack_weights(const float* W, void* out_bf16, int32_t Cout, int32_t Cin, int32_t pad_to, int32_t dgrad, void* stream);
-/* Normalize :9-12 (GroupNorm 32 groups, eps 1e-6) [+ swish :5-7]: y bf16; stats: B*64*(1 + ceil(S/2048)) doubles - the first [B][32][2] =
+/* Normalize :9-12 (GroupNorm 32 groups, eps 1e-6) [+ swish :5-7]: y bf16; stats: B*64*(1 + ceil(S/512)) doubles - the first [B][32][2] =
  * {sum, sumsq} are kept for the backward, the rest is scratch for the per-block partials of the deterministic (atomic-free) reduction */
 int rald_op_groupnorm(const float* x, const float* gamma, const float* beta, void* y_bf16, double* stats, int32_t B, int32_t S, int32_t C,
                       int32_t swish, void* stream);

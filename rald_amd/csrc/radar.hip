@@ -77,7 +77,18 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     const int v0 = blockIdx.x * vox_per_block;
     const int v1 = min(S, v0 + vox_per_block);
     float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;         // channel pairs (4q,4q+1) and (4q+2,4q+3)
-    for (int v = v0 + threadIdx.x / quads; v < v1; v += vstep) {
+    int v = v0 + threadIdx.x / quads;
+    for (; v + 3 * vstep < v1; v += 4 * vstep) {           // four loads in flight per lane (the loop is latency-bound otherwise)
+        float4 t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = reinterpret_cast<const float4*>(x + ((int64_t)b * S + v + u * vstep) * C)[q];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s0 += t[u].x + t[u].y; q0 += t[u].x * t[u].x + t[u].y * t[u].y;
+            s1 += t[u].z + t[u].w; q1 += t[u].z * t[u].z + t[u].w * t[u].w;
+        }
+    }
+    for (; v < v1; v += vstep) {
         const float4 t = reinterpret_cast<const float4*>(x + ((int64_t)b * S + v) * C)[q];
         s0 += t.x + t.y; q0 += t.x * t.x + t.y * t.y;
         s1 += t.z + t.w; q1 += t.z * t.z + t.w * t.w;
@@ -85,25 +96,40 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     sp[threadIdx.x] = make_float4(s0, q0, s1, q1);
     __syncthreads();
     if (threadIdx.x < 32) {
-        const int g = threadIdx.x, cpg = C / 32;
+        // C is 64 * 2^k (host-checked): channels per group cpg = 2^lcpg >= 2.  Group g owns quads [g*cpg/4, (g+1)*cpg/4) of every
+        // voxel row of the block (cpg = 2: one half of quad g/2); visit exactly those, rows then quads, in a fixed order
+        const int g = threadIdx.x, lcpg = 31 - __clz(C / 32), rows = 256 / quads;
+        const int tq0 = lcpg >= 2 ? g << (lcpg - 2) : g >> 1, tq1 = lcpg >= 2 ? (g + 1) << (lcpg - 2) : tq0 + 1;
         double su = 0.0, sq = 0.0;
-        for (int t = 0; t < 256; ++t) {                    // fixed order over the block's threads
-            const int tq = t % quads;
-            const float4 p = sp[t];
-            if ((4 * tq) / cpg == g) { su += (double)p.x; sq += (double)p.y; }
-            if ((4 * tq + 2) / cpg == g) { su += (double)p.z; sq += (double)p.w; }
-        }
+        for (int r = 0; r < rows; ++r)
+            for (int tq = tq0; tq < tq1; ++tq) {
+                const float4 p = sp[r * quads + tq];
+                if (lcpg >= 2 || !(g & 1)) { su += (double)p.x; sq += (double)p.y; }
+                if (lcpg >= 2 || (g & 1)) { su += (double)p.z; sq += (double)p.w; }
+            }
         double* o = part + (((int64_t)b * gridDim.x + blockIdx.x) * 32 + g) * 2;
         o[0] = su; o[1] = sq;
     }
 }
-__global__ __launch_bounds__(64) void gn_finish_kernel(const double* __restrict__ part, double* __restrict__ stats, int nblk) {
-    const int b = blockIdx.x, g = threadIdx.x >> 1, w = threadIdx.x & 1;
+// stats[b][g] = sum over the sample's partial slots part[b*nblk + k][g] (statistics blocks or conv tiles) in a fixed order:
+// sixteen contiguous ranges in parallel (threads 64q .. 64q+63), then the ranges in order
+__global__ __launch_bounds__(1024) void gn_finish_kernel(const double* __restrict__ part, double* __restrict__ stats, int nblk) {
+    __shared__ double sq[16][64];
+    const int b = blockIdx.x, gw = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int k0 = (int)((int64_t)nblk * q / 16), k1 = (int)((int64_t)nblk * (q + 1) / 16);
     double acc = 0.0;
-    for (int k = 0; k < nblk; ++k) acc += part[(((int64_t)b * nblk + k) * 32 + g) * 2 + w];
-    stats[((int64_t)b * 32 + g) * 2 + w] = acc;
+#pragma unroll 4
+    for (int k = k0; k < k1; ++k) acc += part[((int64_t)b * nblk + k) * 64 + gw];
+    sq[q][gw] = acc;
+    __syncthreads();
+    if (q == 0) {
+        double t = sq[0][gw];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) t += sq[i][gw];
+        stats[(int64_t)b * 64 + gw] = t;
+    }
 }
-constexpr int GN_VPB = 2048;                               // voxels per statistics block
+constexpr int GN_VPB = 512;                                // voxels per statistics block
 static inline int gn_blocks(int S) { return (S + GN_VPB - 1) / GN_VPB; }
 
 // y_bf16 = act(GroupNorm(x)) with per-channel affine; act = swish (x*sigmoid(x), :5-7) or identity.
@@ -153,6 +179,10 @@ struct ConvArgs {
     const float* resid;  // [M][Cout] or nullptr
     float* out;          // [M][Cout]
     int B, ID, IH, IW, Cin, OD, OH, OW, Cout, stride, pad;
+    // optional: GroupNorm(32) partial statistics of the OUTPUT, one slot per 128-voxel tile (requires OD*OH*OW % 128 == 0 so that
+    // no tile straddles two samples): gn_part[tile][32 groups][2] doubles = {sum, sumsq}; saves the statistics pass over the fp32
+    // activation (537 MB at full resolution, B = 8) that the next GroupNorm would otherwise make
+    double* gn_part = nullptr;
 };
 
 __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvArgs a) {
@@ -254,6 +284,11 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvArgs a) {
         if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();
     }
+    float cs[NT][4], cq[NT][4];                 // per-lane channel sums over this lane's MT voxels (GroupNorm partials)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cs[j][e] = 0.f; cq[j][e] = 0.f; }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int64_t m = m0 + wm * (BM / 2) + i * 16 + fr;
@@ -270,10 +305,34 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvArgs a) {
                 o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
             }
             *reinterpret_cast<float4*>(a.out + m * a.Cout + n) = o;
+            cs[j][0] += o.x; cs[j][1] += o.y; cs[j][2] += o.z; cs[j][3] += o.w;
+            cq[j][0] += o.x * o.x; cq[j][1] += o.y * o.y; cq[j][2] += o.z * o.z; cq[j][3] += o.w * o.w;
+        }
+    }
+    if (a.gn_part) {
+        // fixed-shape reduction (bit-reproducible): 16 voxel lanes by butterfly, the two voxel halves (wm) and the channels of a
+        // group in index order.  Host contract: full tiles (M % 128 == 0, Cout % 64 == 0), the K-loop's last barrier has passed.
+        float2* sc = reinterpret_cast<float2*>(smem);                       // [wm][64 channels of this n-tile]
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s1 = cs[j][e], s2 = cq[j][e];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                if (fr == 0) sc[wm * 64 + wn * 32 + j * 16 + 4 * fq + e] = make_float2(s1, s2);
+            }
+        __syncthreads();
+        const int cpg = a.Cout / 32, gpt = 64 / cpg;                         // channels per group, groups in this 64-channel tile
+        if (tid < gpt) {
+            double su = 0.0, sq = 0.0;
+            for (int w = 0; w < 2; ++w)
+                for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { su += (double)sc[w * 64 + c].x; sq += (double)sc[w * 64 + c].y; }
+            double* o = a.gn_part + ((int64_t)blockIdx.y * 32 + n0 / cpg + tid) * 2;
+            o[0] = su; o[1] = sq;
         }
     }
 }
-
 // tokens[b][t][c] = z[b][t][:].Wp[c][:] + bp[c] + r_emb[r][c] + a_emb[a][c] + e_emb[e][c], t = (r*A + a)*E + e
 __global__ void radar_token_kernel(const float* __restrict__ z, const float* __restrict__ Wp, const float* __restrict__ bp,
                                    const float* __restrict__ re, const float* __restrict__ ae, const float* __restrict__ ee,
@@ -307,6 +366,10 @@ struct RadarEncoder::Impl {
     bf16 *n16 = nullptr, *q16 = nullptr, *k16 = nullptr, *vt16 = nullptr, *p16 = nullptr, *o16 = nullptr;
     double* stats = nullptr;
     int gn_part_blocks = 0;
+    double* cpart = nullptr;            // per-tile GroupNorm partials written by the conv epilogue
+    size_t cpart_bytes = 0;
+    const float* fused_src = nullptr;   // activation whose partials sit in cpart (nullptr: none)
+    int fused_B = 0, fused_S = 0, fused_C = 0;
     int tok_batch = 0;
 
     void add(const std::string& name, Kind k, int cout, int cin) { tensors[name] = Tensor{k, cout, cin}; }
@@ -445,7 +508,7 @@ int RadarEncoder::load_token_weight(const std::string& name, const float* data, 
 int RadarEncoder::Impl::ensure_ws(int nsub) {
     if (nsub <= sub) return 0;
     RALD_HIP(hipDeviceSynchronize());
-    for (void* p : {(void*)f0, (void*)f1, (void*)f2, (void*)n16, (void*)stats, (void*)q16, (void*)k16, (void*)vt16, (void*)p16, (void*)o16, (void*)sbuf})
+    for (void* p : {(void*)f0, (void*)f1, (void*)f2, (void*)n16, (void*)stats, (void*)cpart, (void*)q16, (void*)k16, (void*)vt16, (void*)p16, (void*)o16, (void*)sbuf})
         if (p) arena->release(p);
     const size_t vox = (size_t)R * A * E;
     const size_t act = (size_t)nsub * vox * ch;                 // level-0 activation (the largest)
@@ -456,22 +519,30 @@ int RadarEncoder::Impl::ensure_ws(int nsub) {
     n16 = (bf16*)arena->alloc(act * 2, true);
     gn_part_blocks = gn_blocks((int)vox);
     stats = (double*)arena->alloc((size_t)nsub * 64 * (1 + gn_part_blocks) * 8, true);   // final {sum, sumsq} + per-block partials
+    cpart_bytes = (size_t)nsub * (vox / 128) * 64 * 8;
+    cpart = (double*)arena->alloc(cpart_bytes, true);
     q16 = (bf16*)arena->alloc((size_t)nsub * ntok * cl * 2, true);
     k16 = (bf16*)arena->alloc((size_t)nsub * ntok * cl * 2, true);
     vt16 = (bf16*)arena->alloc((size_t)nsub * cl * ntok * 2, true);
     p16 = (bf16*)arena->alloc((size_t)nsub * ntok * ntok * 2, true);
     o16 = (bf16*)arena->alloc((size_t)nsub * ntok * cl * 2, true);
     sbuf = (float*)arena->alloc((size_t)nsub * ntok * ntok * 4, true);
-    RALD_CHECK(f0 && f1 && f2 && n16 && stats && q16 && k16 && vt16 && p16 && o16 && sbuf, "radar encoder: workspace allocation failed");
+    RALD_CHECK(f0 && f1 && f2 && n16 && stats && cpart && q16 && k16 && vt16 && p16 && o16 && sbuf, "radar encoder: workspace allocation failed");
     sub = nsub;
     return 0;
 }
 
 int RadarEncoder::Impl::gn(const float* x, const std::string& name, bf16* y, int B, int S, int C, bool swish, hipStream_t st) {
     RALD_CHECK(gn_blocks(S) <= gn_part_blocks, "radar encoder: GroupNorm partial buffer too small");
-    double* part = stats + (size_t)B * 64;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(gn_blocks(S), B), dim3(256), 0, st, x, part, S, C, GN_VPB);
-    hipLaunchKernelGGL(gn_finish_kernel, dim3(B), dim3(64), 0, st, part, stats, gn_blocks(S));
+    static const bool fuse = !(getenv("RALD_GN_FUSE") && atoi(getenv("RALD_GN_FUSE")) == 0);   // A/B switch
+    if (fuse && x == fused_src && B == fused_B && S == fused_S && C == fused_C) {
+        // the convolution that produced x left per-tile partials: no statistics pass over x
+        hipLaunchKernelGGL(gn_finish_kernel, dim3(B), dim3(1024), 0, st, cpart, stats, S / 128);
+    } else {
+        double* part = stats + (size_t)B * 64;
+        hipLaunchKernelGGL(gn_stats_kernel, dim3(gn_blocks(S), B), dim3(256), 0, st, x, part, S, C, GN_VPB);
+        hipLaunchKernelGGL(gn_finish_kernel, dim3(B), dim3(1024), 0, st, part, stats, gn_blocks(S));
+    }
     const int64_t quads = (int64_t)S * C / 4;
     const int blocks = (int)((quads + 255) / 256 < 1024 ? (quads + 255) / 256 : 1024);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, B), dim3(256), 0, st, x, stats, P<float>(name + ".weight"), P<float>(name + ".bias"), y,
@@ -488,6 +559,13 @@ int RadarEncoder::Impl::run_conv(const bf16* in, const std::string& name, const 
     a.OD = ID / stride; a.OH = IH / stride; a.OW = IW / stride;
     RALD_CHECK(cin % 64 == 0 && cout % 4 == 0, "conv3d: Cin must be a multiple of 64 and Cout of 4");
     const int64_t M = (int64_t)B * a.OD * a.OH * a.OW;
+    const int So = a.OD * a.OH * a.OW;
+    if (out == f0 || out == f1 || out == f2) {
+        if (So % 128 == 0 && cout % 64 == 0 && (cout == 64 || cout == 128 || cout == 256) && (size_t)B * (So / 128) * 64 * 8 <= cpart_bytes) {
+            a.gn_part = cpart;
+            fused_src = out; fused_B = B; fused_S = So; fused_C = cout;
+        } else if (out == fused_src) fused_src = nullptr;      // this buffer is being overwritten without new partials
+    }
     hipLaunchKernelGGL(conv3d_igemm_kernel, dim3(cdiv(cout, 64), (unsigned)((M + 127) / 128)), dim3(256), 0, st, a);
     RALD_HIP(hipGetLastError());
     return 0;
@@ -504,6 +582,7 @@ int RadarEncoder::Impl::resblock(float*& x, float*& t1, float*& t2, const std::s
         RALD_TRY(cast_f32_bf16(x, n16, (int64_t)B * S * cin, st));
         GemmArgs g = gemm_args(n16, cin, P<bf16>(name + ".nin_shortcut.weight"), cin, t2, cout, P<float>(name + ".nin_shortcut.bias"), B * S, cout, cin);
         RALD_TRY(gemm_nt(g, EPI_F32, st));
+        if (t2 == fused_src) fused_src = nullptr;
         res = t2;
     }
     RALD_TRY(gn(t1, name + ".norm2", n16, B, S, cout, true, st));
@@ -534,6 +613,7 @@ int RadarEncoder::Impl::attnblock(float* x, const std::string& name, int B, int 
     RALD_TRY(gemm_nt(pv, EPI_BF16, st));
     GemmArgs o = gemm_args(o16, C, P<bf16>(name + ".proj_out.weight"), C, x, C, P<float>(name + ".proj_out.bias"), B * S, C, C);
     RALD_TRY(gemm_nt(o, EPI_RESID, st));
+    if (x == fused_src) fused_src = nullptr;                  // x changed in place: its conv partials are stale
     return 0;
 }
 
@@ -541,6 +621,7 @@ int RadarEncoder::Impl::forward(const float* cube, int cube_ch, int B, float* zo
     for (const auto& kv : tensors) RALD_CHECK(kv.second.loaded, "radar encoder: missing key '" + kv.first + "'");
     RALD_TRY(ensure_ws(B));
     float *x = f0, *t1 = f1, *t2 = f2;
+    fused_src = nullptr;
     int Dd = R, Hh = A, Ww = E;
     {
         const int groups = ch / 8, vpb = 256 / groups;
@@ -634,9 +715,9 @@ int groupnorm_fwd(const float* x, const float* gamma, const float* beta, bf16* y
                   hipStream_t st) {
     RALD_CHECK(x && gamma && beta && y && stats, "groupnorm: null pointer");
     RALD_CHECK(B > 0 && S > 0 && C % 64 == 0 && 256 % (C / 4) == 0, "groupnorm: channel count must be 64, 128 or 256");
-    double* part = stats + (size_t)B * 64;                 // caller contract: B*64*(1 + ceil(S/2048)) doubles
+    double* part = stats + (size_t)B * 64;                 // caller contract: B*64*(1 + ceil(S/512)) doubles
     hipLaunchKernelGGL(gn_stats_kernel, dim3(gn_blocks(S), B), dim3(256), 0, st, x, part, S, C, GN_VPB);
-    hipLaunchKernelGGL(gn_finish_kernel, dim3(B), dim3(64), 0, st, part, stats, gn_blocks(S));
+    hipLaunchKernelGGL(gn_finish_kernel, dim3(B), dim3(1024), 0, st, part, stats, gn_blocks(S));
     const int64_t quads = (int64_t)S * C / 4;
     const int blocks = (int)((quads + 255) / 256 < 1024 ? (quads + 255) / 256 : 1024);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, B), dim3(256), 0, st, x, stats, gamma, beta, y, S, C, 1e-6f, swish ? 1 : 0);

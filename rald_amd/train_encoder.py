@@ -57,7 +57,7 @@ def groupnorm(x: torch.Tensor, gamma, beta, swish: bool):
     B, Cc = x.shape[0], x.shape[-1]
     S = x.numel() // (B * Cc)
     y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
-    buf = torch.empty(B * 64 * (1 + (S + 2047) // 2048), device=x.device, dtype=torch.float64)   # stats + per-block partials
+    buf = torch.empty(B * 64 * (1 + (S + 511) // 512), device=x.device, dtype=torch.float64)   # stats + per-block partials
     check(lib().rald_op_groupnorm(_p(x), _p(gamma), _p(beta), _p(y), _p(buf), B, S, Cc, int(swish), _st()))
     return y, buf[:B * 64].view(B, 32, 2)
 
