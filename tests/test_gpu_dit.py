@@ -78,3 +78,7 @@ def test_batch_independence_and_b1():
     full = m(x, t, cond=cond)
     one = m(x[3:4], t, cond=cond[3:4])
     assert rel_l2(one, full[3:4]) < 4e-3
+    # B = 8 (4 096 rows: the split-K feed-forward tail and the mid-size GEMM engines) against the same rows of B = 5
+    x8, cond8 = synth.latents(range(8)).cuda(), synth.cond_tokens(8).cuda()
+    full8 = m(x8, t, cond=cond8)
+    assert rel_l2(full8[:5], full) < 4e-3

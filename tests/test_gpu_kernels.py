@@ -206,7 +206,7 @@ def test_attention_row_major_v_transposed_lds_read(H):
     assert torch.equal(out, old)                                   # same arithmetic, different operand path
 
 
-@pytest.mark.parametrize("M,K", [(512, 512), (1000, 2048), (32768, 512), (32768, 2048)])
+@pytest.mark.parametrize("M,K", [(512, 512), (1000, 2048), (32768, 512), (32768, 2048), (640, 256), (300, 576), (25000, 64), (24704, 576)])
 def test_gemm_residual_with_fused_layernorm(H, M, K):
     """x += A.W^T + bias and the next (Ada)LayerNorm in one kernel: both outputs against fp32 torch,
     with per-group modulation rows (AdaLN, add_one = 1) - 64-row and 128-row tile configurations."""
