@@ -185,6 +185,62 @@ struct ConvArgs {
     double* gn_part = nullptr;
 };
 
+// Epilogue shared by the two convolution kernels: bias (+ fp32 residual), fp32 store, optional GroupNorm partials of the output.
+// acc[i][j][e] <-> voxel m0 + wm*64 + i*16 + fr, channel n0 + wn*32 + j*16 + 4*fq + e.  Must be reached by the whole workgroup
+// after the K-loop's last barrier (it reuses the staging LDS when a.gn_part is set).
+__device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[4][2], const ConvArgs& a, int64_t M, int64_t m0, int n0, int wm, int wn, int fr,
+                                              int fq, int tid, unsigned char* smem) {
+    constexpr int BM = 128, BN = 64, MT = 4, NT = 2;
+    float cs[NT][4], cq[NT][4];                 // per-lane channel sums over this lane's MT voxels (GroupNorm partials)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cs[j][e] = 0.f; cq[j][e] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int64_t m = m0 + wm * (BM / 2) + i * 16 + fr;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 16 + 4 * fq;
+            if (n >= a.Cout) continue;
+            const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+            f32x4 v = acc[i][j];
+            float4 o = make_float4(v[0] + b.x, v[1] + b.y, v[2] + b.z, v[3] + b.w);
+            if (a.resid) {
+                const float4 r = *reinterpret_cast<const float4*>(a.resid + m * a.Cout + n);
+                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            }
+            *reinterpret_cast<float4*>(a.out + m * a.Cout + n) = o;
+            cs[j][0] += o.x; cs[j][1] += o.y; cs[j][2] += o.z; cs[j][3] += o.w;
+            cq[j][0] += o.x * o.x; cq[j][1] += o.y * o.y; cq[j][2] += o.z * o.z; cq[j][3] += o.w * o.w;
+        }
+    }
+    if (a.gn_part) {
+        // fixed-shape reduction (bit-reproducible): 16 voxel lanes by butterfly, the two voxel halves (wm) and the channels of a
+        // group in index order.  Host contract: full tiles (M % 128 == 0, Cout % 64 == 0), the K-loop's last barrier has passed.
+        float2* sc = reinterpret_cast<float2*>(smem);                       // [wm][64 channels of this n-tile]
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s1 = cs[j][e], s2 = cq[j][e];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                if (fr == 0) sc[wm * 64 + wn * 32 + j * 16 + 4 * fq + e] = make_float2(s1, s2);
+            }
+        __syncthreads();
+        const int cpg = a.Cout / 32, gpt = 64 / cpg;                         // channels per group, groups in this 64-channel tile
+        if (tid < gpt) {
+            double su = 0.0, sq = 0.0;
+            for (int w = 0; w < 2; ++w)
+                for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { su += (double)sc[w * 64 + c].x; sq += (double)sc[w * 64 + c].y; }
+            double* o = a.gn_part + ((int64_t)blockIdx.y * 32 + n0 / cpg + tid) * 2;
+            o[0] = su; o[1] = sq;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvArgs a) {
     constexpr int BM = 128, BN = 64, BK = 64;
     constexpr int MT = BM / 32, NT = BN / 32, PA = BM / 32, PB = BN / 32;
@@ -284,55 +340,167 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvArgs a) {
         if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();
     }
-    float cs[NT][4], cq[NT][4];                 // per-lane channel sums over this lane's MT voxels (GroupNorm partials)
+    conv_epilogue(acc, a, M, m0, n0, wm, wn, fr, fq, tid, smem);
+}
+
+// Stride-1, pad-1 variant that stages whole input LINES.  A tile is 128 consecutive output voxels = L = 128/OW complete w-lines
+// (OW = 2^lw in {8, 16, 32}); for a fixed (kd, kh) the three kw taps read the same L input lines shifted by one voxel, so the
+// lines are staged ONCE with a one-voxel apron (L x (OW+2) rows of 128 B) and the taps index into them: a third of the gathers of
+// conv3d_igemm_kernel, whose full-resolution launches run at the L2 -> CU rate of those gathers.  Same MFMA fragment layout
+// and epilogue.  Host contract: stride 1, pad 1, M % 128 == 0, Cin % 64 == 0.
+__global__ __launch_bounds__(256) void conv3d_line_kernel(ConvArgs a, int lw) {
+    constexpr int BM = 128, BN = 64, BK = 64, MT = 4, NT = 2, PB = 2, RE_MAX = 160, PAX = RE_MAX / 32;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * RE_MAX * 128 + 2 * BN * 128];
+    bf16x8* sA = reinterpret_cast<bf16x8*>(smem);                         // [2][RE_MAX rows][8 chunks]
+    bf16x8* sB = reinterpret_cast<bf16x8*>(smem + 2 * RE_MAX * 128);      // [2][64 couts][8 chunks]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t M = (int64_t)a.B * a.OD * a.OH * a.OW;
+    const int64_t m0 = (int64_t)blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    const int srow = tid >> 3, schunk = tid & 7;
+    const int OW = 1 << lw, EW = OW + 2, RE = (BM >> lw) * EW;
+    // staged row e = srow + 32p -> (line l, apron column we): the line's (b, od, oh) and the input column iw = we - 1
+    int eb[PAX], ed[PAX], eh[PAX], ewi[PAX];
+    const int64_t ln0 = m0 >> lw;
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int p = 0; p < PAX; ++p) {
+        const int e = srow + 32 * p;
+        const int l = e / EW;
+        ewi[p] = e < RE ? e - l * EW - 1 : -2;                               // -2: no such row (never valid)
+        int64_t ln = ln0 + l;
+        const int64_t nlines = (int64_t)a.B * a.OD * a.OH;
+        if (ln >= nlines) ln = nlines - 1;
+        eh[p] = (int)(ln % a.OH);
+        const int64_t r = ln / a.OH;
+        ed[p] = (int)(r % a.OD);
+        eb[p] = (int)(r / a.OD);
+    }
+    const bf16* gB[PB];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { cs[j][e] = 0.f; cq[j][e] = 0.f; }
+    for (int p = 0; p < PB; ++p) {
+        int r = n0 + srow + 32 * p;
+        r = r < a.Cout ? r : a.Cout - 1;
+        gB[p] = a.w + (int64_t)r * 27 * a.Cin + schunk * 8;
+    }
+    const int cpk = a.Cin / BK;
+    const int nsteps = 27 * cpk;                                             // step s = (pair * cpk + c) * 3 + kw, pair = kd*3 + kh
+    // Global loads run TWO k-steps ahead of their first use (a k-step is only 16 MFMAs per wave, far less than one memory
+    // latency): weights in two register sets that alternate by step parity, input lines loaded at kw = 0 of the previous
+    // (kd, kh) pair and written to LDS at its kw = 2.
+    bf16x8 rA[PAX], rB[2][PB];
+    auto load_A = [&](int pc) {                                              // pc = pair * cpk + c
+        const int pair = pc / cpk, c0 = (pc - pair * cpk) * BK;
+        const int kd = pair / 3, kh = pair - 3 * kd;
+#pragma unroll
+        for (int p = 0; p < PAX; ++p) {
+            const int id = ed[p] + kd - 1, ih = eh[p] + kh - 1, iw = ewi[p];
+            bf16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (bf16)0.f;
+            if ((unsigned)id < (unsigned)a.ID && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW)
+                v = *reinterpret_cast<const bf16x8*>(a.in + ((((int64_t)eb[p] * a.ID + id) * a.IH + ih) * a.IW + iw) * a.Cin + c0 + schunk * 8);
+            rA[p] = v;
+        }
+    };
+    auto store_A = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < PAX; ++p) {
+            const int e = srow + 32 * p;
+            if (e < RE) sA[(buf * RE_MAX + e) * 8 + (schunk ^ (e & 7))] = rA[p];
+        }
+    };
+    auto load_B = [&](int s, auto PAR) {
+        constexpr int par = decltype(PAR)::value;
+        const int pc = s / 3, kw = s - 3 * pc;
+        const int pair = pc / cpk, c = pc - pair * cpk;
+        const int kt = (pair * 3 + kw) * cpk + c;                            // weight K index: tap-major, then the Cin chunk
+#pragma unroll
+        for (int p = 0; p < PB; ++p) rB[par][p] = *reinterpret_cast<const bf16x8*>(gB[p] + (int64_t)kt * BK);
+    };
+    auto store_B = [&](int buf, auto PAR) {
+        constexpr int par = decltype(PAR)::value;
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const int r = srow + 32 * p;
+            sB[(buf * BN + r) * 8 + (schunk ^ (r & 7))] = rB[par][p];
+        }
+    };
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    int ebase[MT];                                                           // staged row of this lane's voxel at kw = 0
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        const int64_t m = m0 + wm * (BM / 2) + i * 16 + fr;
-        if (m >= M) continue;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int n = n0 + wn * (BN / 2) + j * 16 + 4 * fq;
-            if (n >= a.Cout) continue;
-            const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
-            f32x4 v = acc[i][j];
-            float4 o = make_float4(v[0] + b.x, v[1] + b.y, v[2] + b.z, v[3] + b.w);
-            if (a.resid) {
-                const float4 r = *reinterpret_cast<const float4*>(a.resid + m * a.Cout + n);
-                o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-            }
-            *reinterpret_cast<float4*>(a.out + m * a.Cout + n) = o;
-            cs[j][0] += o.x; cs[j][1] += o.y; cs[j][2] += o.z; cs[j][3] += o.w;
-            cq[j][0] += o.x * o.x; cq[j][1] += o.y * o.y; cq[j][2] += o.z * o.z; cq[j][3] += o.w * o.w;
-        }
+        const int r = wm * (BM / 2) + i * 16 + fr;
+        ebase[i] = (r >> lw) * EW + (r & (OW - 1));
     }
-    if (a.gn_part) {
-        // fixed-shape reduction (bit-reproducible): 16 voxel lanes by butterfly, the two voxel halves (wm) and the channels of a
-        // group in index order.  Host contract: full tiles (M % 128 == 0, Cout % 64 == 0), the K-loop's last barrier has passed.
-        float2* sc = reinterpret_cast<float2*>(smem);                       // [wm][64 channels of this n-tile]
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    const int npc = 9 * cpk;
+    load_A(0); load_B(0, P0{});
+    store_A(0); store_B(0, P0{});
+    if (nsteps > 1) load_B(1, P1{});
+    if (npc > 1) load_A(1);
+    __syncthreads();
+    // one k-step; KW = s % 3, PAR = s & 1 (compile-time so that the register sets are not indexed dynamically)
+    auto step = [&](int pc, auto KWC, auto PARC) {
+        constexpr int kw = decltype(KWC)::value, par = decltype(PARC)::value;
+        const int s = 3 * pc + kw;
+        const int abuf = pc & 1;
+        if (s + 2 < nsteps) load_B(s + 2, PARC);                             // set `par` held B(s), already in LDS
+        if (kw == 0 && pc >= 1 && pc + 1 < npc) load_A(pc + 1);               // (pc = 0: issued in the prologue)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[MT], fb[NT];
+            const int chunk = kk * 4 + fq;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float s1 = cs[j][e], s2 = cq[j][e];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-                if (fr == 0) sc[wm * 64 + wn * 32 + j * 16 + 4 * fq + e] = make_float2(s1, s2);
+            for (int i = 0; i < MT; ++i) {
+                const int e = ebase[i] + kw;
+                fa[i] = sA[(abuf * RE_MAX + e) * 8 + (chunk ^ (e & 7))];
             }
-        __syncthreads();
-        const int cpg = a.Cout / 32, gpt = 64 / cpg;                         // channels per group, groups in this 64-channel tile
-        if (tid < gpt) {
-            double su = 0.0, sq = 0.0;
-            for (int w = 0; w < 2; ++w)
-                for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { su += (double)sc[w * 64 + c].x; sq += (double)sc[w * 64 + c].y; }
-            double* o = a.gn_part + ((int64_t)blockIdx.y * 32 + n0 / cpg + tid) * 2;
-            o[0] = su; o[1] = sq;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int r = wn * (BN / 2) + j * 16 + fr;
+                fb[j] = sB[(par * BN + r) * 8 + (chunk ^ (r & 7))];
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
+        if (s + 1 < nsteps) store_B(par ^ 1, std::integral_constant<int, par ^ 1>{});   // B(s+1), loaded one step ago
+        if (kw == 2 && pc + 1 < npc) store_A(abuf ^ 1);                       // lines of the next pair, loaded at its kw = 0
+        __syncthreads();
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+    for (int pc = 0; pc < npc; pc += 2) {                                    // s = 3 pc + kw: parity (pc + kw) & 1
+        step(pc, K0{}, P0{}); step(pc, K1{}, P1{}); step(pc, K2{}, P0{});
+        if (pc + 1 < npc) { step(pc + 1, K0{}, P1{}); step(pc + 1, K1{}, P0{}); step(pc + 1, K2{}, P1{}); }
+    }
+    conv_epilogue(acc, a, M, m0, n0, wm, wn, fr, fq, tid, smem);
+}
+
+// engine choice for one convolution (RALD_CONV_LINE=0 keeps the per-tap gather kernel everywhere: A/B switch)
+static void launch_conv(const ConvArgs& a, hipStream_t st) {
+    static const bool line = !(getenv("RALD_CONV_LINE") && atoi(getenv("RALD_CONV_LINE")) == 0);
+    const int64_t M = (int64_t)a.B * a.OD * a.OH * a.OW;
+    const dim3 grid(cdiv(a.Cout, 64), (unsigned)((M + 127) / 128));
+    const bool pow2 = a.OW == 8 || a.OW == 16 || a.OW == 32;
+    if (line && a.stride == 1 && a.pad == 1 && pow2 && M % 128 == 0 && a.Cin % 64 == 0 && a.OD == a.ID && a.OH == a.IH && a.OW == a.IW) {
+        const int lw = a.OW == 8 ? 3 : a.OW == 16 ? 4 : 5;
+        hipLaunchKernelGGL(conv3d_line_kernel, grid, dim3(256), 0, st, a, lw);
+    } else {
+        hipLaunchKernelGGL(conv3d_igemm_kernel, grid, dim3(256), 0, st, a);
     }
 }
+
 // tokens[b][t][c] = z[b][t][:].Wp[c][:] + bp[c] + r_emb[r][c] + a_emb[a][c] + e_emb[e][c], t = (r*A + a)*E + e
 __global__ void radar_token_kernel(const float* __restrict__ z, const float* __restrict__ Wp, const float* __restrict__ bp,
                                    const float* __restrict__ re, const float* __restrict__ ae, const float* __restrict__ ee,
@@ -566,7 +734,8 @@ int RadarEncoder::Impl::run_conv(const bf16* in, const std::string& name, const 
             fused_src = out; fused_B = B; fused_S = So; fused_C = cout;
         } else if (out == fused_src) fused_src = nullptr;      // this buffer is being overwritten without new partials
     }
-    hipLaunchKernelGGL(conv3d_igemm_kernel, dim3(cdiv(cout, 64), (unsigned)((M + 127) / 128)), dim3(256), 0, st, a);
+    (void)M;
+    launch_conv(a, st);
     RALD_HIP(hipGetLastError());
     return 0;
 }
@@ -705,8 +874,7 @@ int conv3d_igemm(const bf16* in, const bf16* w_packed, const float* bias, const 
     a.in = in; a.w = w_packed; a.bias = bias; a.resid = resid; a.out = out;
     a.B = B; a.ID = ID; a.IH = IH; a.IW = IW; a.Cin = Cin; a.Cout = Cout; a.stride = stride; a.pad = pad;
     a.OD = ID / stride; a.OH = IH / stride; a.OW = IW / stride;
-    const int64_t M = (int64_t)B * a.OD * a.OH * a.OW;
-    hipLaunchKernelGGL(conv3d_igemm_kernel, dim3(cdiv(Cout, 64), (unsigned)((M + 127) / 128)), dim3(256), 0, st, a);
+    launch_conv(a, st);
     RALD_HIP(hipGetLastError());
     return 0;
 }
