@@ -183,6 +183,9 @@ struct ConvArgs {
     // no tile straddles two samples): gn_part[tile][32 groups][2] doubles = {sum, sumsq}; saves the statistics pass over the fp32
     // activation (537 MB at full resolution, B = 8) that the next GroupNorm would otherwise make
     double* gn_part = nullptr;
+    // optional split-K (few tiles, long K: the 64- and 512-voxel levels): gridDim.z workgroups share a tile, each takes a contiguous
+    // range of k-steps and writes its raw accumulators to split_part[z][M][Cout]; conv_split_reduce_kernel adds them in order
+    float* split_part = nullptr;
 };
 
 // Epilogue shared by the two convolution kernels: bias (+ fp32 residual), fp32 store, optional GroupNorm partials of the output.
@@ -310,13 +313,14 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvArgs a) {
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    load_tile(0);
-    store_tile(0);
+    const int k_begin = (int)((int64_t)nk * blockIdx.z / gridDim.z), k_end = (int)((int64_t)nk * (blockIdx.z + 1) / gridDim.z);
+    load_tile(k_begin);
+    store_tile(k_begin & 1);
     __syncthreads();
     const int fr = lane & 15, fq = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = k_begin; kt < k_end; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+        if (kt + 1 < k_end) load_tile(kt + 1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 fa[MT], fb[NT];
@@ -337,10 +341,44 @@ __global__ __launch_bounds__(256) void conv3d_igemm_kernel(ConvArgs a) {
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+        if (kt + 1 < k_end) store_tile(buf ^ 1);
         __syncthreads();
     }
+    if (a.split_part) {                          // raw partial sums of this k-range (bias / residual are added by the reduce pass)
+        float* part = a.split_part + (int64_t)blockIdx.z * M * a.Cout;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int64_t m = m0 + wm * (BM / 2) + i * 16 + fr;
+            if (m >= M) continue;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 16 + 4 * fq;
+                if (n >= a.Cout) continue;
+                *reinterpret_cast<float4*>(part + m * a.Cout + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+        }
+        return;
+    }
     conv_epilogue(acc, a, M, m0, n0, wm, wn, fr, fq, tid, smem);
+}
+// out = bias + sum_z part[z] (+ resid), z in order; one float4 per thread
+__global__ __launch_bounds__(256) void conv_split_reduce_kernel(const float* __restrict__ part, int splits, int64_t MC, int Cout,
+                                                                const float* __restrict__ bias, const float* __restrict__ resid,
+                                                                float* __restrict__ out) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= MC) return;
+    const float4 b = *reinterpret_cast<const float4*>(bias + (int)(i % Cout));
+    float4 acc = *reinterpret_cast<const float4*>(part + i);
+    for (int z = 1; z < splits; ++z) {
+        const float4 p = *reinterpret_cast<const float4*>(part + (int64_t)z * MC + i);
+        acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+    }
+    acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+    if (resid) {
+        const float4 r = *reinterpret_cast<const float4*>(resid + i);
+        acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+    }
+    *reinterpret_cast<float4*>(out + i) = acc;
 }
 
 // Stride-1, pad-1 variant that stages whole input LINES.  A tile is 128 consecutive output voxels = L = 128/OW complete w-lines
@@ -536,6 +574,8 @@ struct RadarEncoder::Impl {
     int gn_part_blocks = 0;
     double* cpart = nullptr;            // per-tile GroupNorm partials written by the conv epilogue
     size_t cpart_bytes = 0;
+    float* spart = nullptr;             // split-K partial accumulators of the small-level convolutions
+    size_t spart_bytes = 0;
     const float* fused_src = nullptr;   // activation whose partials sit in cpart (nullptr: none)
     int fused_B = 0, fused_S = 0, fused_C = 0;
     int tok_batch = 0;
@@ -676,7 +716,7 @@ int RadarEncoder::load_token_weight(const std::string& name, const float* data, 
 int RadarEncoder::Impl::ensure_ws(int nsub) {
     if (nsub <= sub) return 0;
     RALD_HIP(hipDeviceSynchronize());
-    for (void* p : {(void*)f0, (void*)f1, (void*)f2, (void*)n16, (void*)stats, (void*)cpart, (void*)q16, (void*)k16, (void*)vt16, (void*)p16, (void*)o16, (void*)sbuf})
+    for (void* p : {(void*)f0, (void*)f1, (void*)f2, (void*)n16, (void*)stats, (void*)cpart, (void*)spart, (void*)q16, (void*)k16, (void*)vt16, (void*)p16, (void*)o16, (void*)sbuf})
         if (p) arena->release(p);
     const size_t vox = (size_t)R * A * E;
     const size_t act = (size_t)nsub * vox * ch;                 // level-0 activation (the largest)
@@ -687,6 +727,8 @@ int RadarEncoder::Impl::ensure_ws(int nsub) {
     n16 = (bf16*)arena->alloc(act * 2, true);
     gn_part_blocks = gn_blocks((int)vox);
     stats = (double*)arena->alloc((size_t)nsub * 64 * (1 + gn_part_blocks) * 8, true);   // final {sum, sumsq} + per-block partials
+    spart_bytes = (size_t)8 << 20;                              // splits * tiles <= 256 tiles of 128 x 64 fp32
+    spart = (float*)arena->alloc(spart_bytes, true);
     cpart_bytes = (size_t)nsub * (vox / 128) * 64 * 8;
     cpart = (double*)arena->alloc(cpart_bytes, true);
     q16 = (bf16*)arena->alloc((size_t)nsub * ntok * cl * 2, true);
@@ -695,7 +737,7 @@ int RadarEncoder::Impl::ensure_ws(int nsub) {
     p16 = (bf16*)arena->alloc((size_t)nsub * ntok * ntok * 2, true);
     o16 = (bf16*)arena->alloc((size_t)nsub * ntok * cl * 2, true);
     sbuf = (float*)arena->alloc((size_t)nsub * ntok * ntok * 4, true);
-    RALD_CHECK(f0 && f1 && f2 && n16 && stats && cpart && q16 && k16 && vt16 && p16 && o16 && sbuf, "radar encoder: workspace allocation failed");
+    RALD_CHECK(f0 && f1 && f2 && n16 && stats && cpart && spart && q16 && k16 && vt16 && p16 && o16 && sbuf, "radar encoder: workspace allocation failed");
     sub = nsub;
     return 0;
 }
@@ -728,6 +770,26 @@ int RadarEncoder::Impl::run_conv(const bf16* in, const std::string& name, const 
     RALD_CHECK(cin % 64 == 0 && cout % 4 == 0, "conv3d: Cin must be a multiple of 64 and Cout of 4");
     const int64_t M = (int64_t)B * a.OD * a.OH * a.OW;
     const int So = a.OD * a.OH * a.OW;
+    // few tiles x long K (the 512- and 64-voxel levels: 8-64 workgroups looping over 54-108 k-steps): split K over gridDim.z
+    static const bool split_ok = !(getenv("RALD_CONV_SPLITK") && atoi(getenv("RALD_CONV_SPLITK")) == 0);   // A/B switch
+    const int64_t tiles = (int64_t)cdiv(cout, 64) * ((M + 127) / 128);
+    const int nk = 27 * (cin / 64);
+    const bool line_engine = stride == 1 && pad == 1 && (a.OW == 8 || a.OW == 16 || a.OW == 32) && M % 128 == 0;
+    if (split_ok && !line_engine && tiles <= 64 && nk >= 12 && cout % 4 == 0) {
+        int splits = (int)(256 / tiles);
+        if (splits > 16) splits = 16;
+        if (splits > nk / 3) splits = nk / 3;
+        if (splits >= 2 && (size_t)splits * M * cout * 4 <= spart_bytes) {
+            if (out == fused_src) fused_src = nullptr;         // no GroupNorm partials from this path
+            a.split_part = spart;
+            hipLaunchKernelGGL(conv3d_igemm_kernel, dim3(cdiv(cout, 64), (unsigned)((M + 127) / 128), splits), dim3(256), 0, st, a);
+            const int64_t MC = M * cout;
+            hipLaunchKernelGGL(conv_split_reduce_kernel, dim3((unsigned)((MC / 4 + 255) / 256)), dim3(256), 0, st, spart, splits, MC, cout,
+                               a.bias, resid, out);
+            RALD_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     if (out == f0 || out == f1 || out == f2) {
         if (So % 128 == 0 && cout % 64 == 0 && (cout == 64 || cout == 128 || cout == 256) && (size_t)B * (So / 128) * 64 * 8 <= cpart_bytes) {
             a.gn_part = cpart;
