@@ -238,13 +238,13 @@ class EDMPrecond(_HipBacked):
             self._hip, self._hip_fp, self._cond_memo = h, fp, None
         return self._hip
 
-    def _cond(self, cube: torch.Tensor):
+    def _cond(self, cube: torch.Tensor, h: "DitHandle | None" = None):
         """(tokens, cond cache) for a radar cube; memoised on the tensor identity so a caller that
         invokes forward() in a loop with the same cube (the reference's sampler does, re-running
         the 287-GFLOP encoder every NFE) encodes it once."""
         key = (cube.data_ptr(), cube._version, tuple(cube.shape))
         if self._cond_memo is None or self._cond_memo[0] != key:
-            tokens, cache = self._handle().encode_cond(cube)
+            tokens, cache = (h or self._handle()).encode_cond(cube)      # (h: the caller already paid the 1.6 ms fingerprint walk)
             self._cond_memo = (key, tokens, cache)
         return self._cond_memo[1], self._cond_memo[2]
 
@@ -257,7 +257,7 @@ class EDMPrecond(_HipBacked):
         if cond_type != 'radar':
             raise NotImplementedError("cond_type must be 'radar'")
         h = self._handle()
-        _, cache = self._cond(label_tokens)
+        _, cache = self._cond(label_tokens, h)
         sig = torch.as_tensor(sigma, dtype=torch.float32).reshape(-1).cpu()
         if sig.numel() not in (1, x.shape[0]):
             raise RuntimeError("sigma must be a scalar or have one entry per sample")
@@ -271,7 +271,7 @@ class EDMPrecond(_HipBacked):
         if cond_type != 'radar':
             raise NotImplementedError("cond_type must be 'radar'")
         h = self._handle()
-        _, cache = self._cond(cond)
+        _, cache = self._cond(cond, h)
         return h.sample(latents, cache, num_steps, float(sigma_min), float(sigma_max), float(rho))
 
     def _replica(self, i: int) -> DitHandle:
