@@ -60,6 +60,10 @@ int rald_dit_load_weight(rald_dit* h, const char* name, const float* data, int64
 int rald_dit_finalize(rald_dit* h);
 /* Pre-allocates activation workspace for batches up to max_batch (otherwise grown on demand). */
 int rald_dit_reserve(rald_dit* h, int32_t max_batch);
+/* Counts the reallocations of handle-owned device buffers (activation workspace, noise-level tables).  A caller that
+ * captured library calls into a hipGraph must re-capture when the value differs from the one read after capture: the
+ * graph's kernels hold pointers into those buffers. */
+int64_t rald_dit_workspace_generation(const rald_dit* h);
 
 /* Noise-level table: for each of the n sigmas (HOST array) computes the EDM coefficients
  * (c_in, c_skip, c_out, c_noise; :422-425), the timestep embedding (:217-219) and all
@@ -96,7 +100,7 @@ int rald_dit_profile_begin(rald_dit* h);
 int rald_dit_profile_end(rald_dit* h, double* total_ms, int32_t* launches);
 
 /* ------------------------------------------------------------------------------------------
- * Set-latent autoencoder: KLAutoEncoder, query_type='mix'  (model/models_ae.py:284-432)
+ * Set-latent autoencoder: KLAutoEncoder, query_type='mix' or 'learnable'  (model/models_ae.py:284-432)
  * ---------------------------------------------------------------------------------------- */
 typedef struct rald_ae rald_ae;
 typedef struct rald_ae_config {
@@ -107,6 +111,8 @@ typedef struct rald_ae_config {
     int32_t heads;        /* 8  (hard-coded :455)                                           */
     int32_t dim_head;     /* 64 (hard-coded :456)                                           */
     int32_t num_inputs;   /* P: encode asserts pc.shape[1] == num_inputs (:354)             */
+    int32_t query_type;   /* 0 = 'mix' (:380-387, the shipped config), 1 = 'learnable' (:378-379: keys `latents.weight`
+                             instead of s_latents / d_latents / mix_attn_layer / query_proj)   */
 } rald_ae_config;
 
 int rald_ae_create(const rald_ae_config* cfg, rald_ae** out);
@@ -125,6 +131,7 @@ int rald_ae_encode(rald_ae* h, const float* pc, int32_t batch, const float* eps,
  * against it (the reference recomputes the 116-GFLOP stack for each of its <=4 decode calls per
  * sample, engine_generation.py:204, :275, :300). */
 int64_t rald_ae_ctx_bytes(const rald_ae* h, int32_t batch);
+int64_t rald_ae_workspace_generation(const rald_ae* h);   /* as rald_dit_workspace_generation */
 int rald_ae_decode_latents(rald_ae* h, const float* z, int32_t batch, void* ctx, void* stream);
 /* queries [B,Q,3] -> occupancy logits [B,Q] (the reference returns [B,Q,1]; occupied iff > 0) */
 int rald_ae_decode_queries(rald_ae* h, const void* ctx, const float* queries, int32_t batch, int64_t n_queries,

@@ -275,13 +275,17 @@ def ae_ff(sd: SD, p: str, x):
 
 
 def ae_encode_moments(sd: SD, pc: torch.Tensor, heads: int = 8):
-    """KLAutoEncoder.encode :351-399 ('mix' query) up to (mean, logvar)."""
+    """KLAutoEncoder.encode :351-399 up to (mean, logvar): the 'mix' query (:380-387) or, when the state dict holds
+    `latents.weight` instead of s_/d_latents, the 'learnable' one (:378-379)."""
     b = pc.shape[0]
     emb = point_embed(sd, pc)
-    s_q = sd["s_latents.weight"][None].expand(b, -1, -1)
-    d_q = sd["d_latents.weight"][None].expand(b, -1, -1)
-    d_q = ae_attention(sd, "mix_attn_layer.", d_q, emb, heads)           # no residual (:384)
-    x = _lin(sd, "query_proj", s_q + d_q)
+    if "latents.weight" in sd:
+        x = sd["latents.weight"][None].expand(b, -1, -1)
+    else:
+        s_q = sd["s_latents.weight"][None].expand(b, -1, -1)
+        d_q = sd["d_latents.weight"][None].expand(b, -1, -1)
+        d_q = ae_attention(sd, "mix_attn_layer.", d_q, emb, heads)       # no residual (:384)
+        x = _lin(sd, "query_proj", s_q + d_q)
     x = ae_attention(sd, "cross_attend_blocks.0.", x, emb, heads=1) + x  # 1 head x dim (:309)
     x = ae_ff(sd, "cross_attend_blocks.1.", x) + x
     return _lin(sd, "mean_fc", x), _lin(sd, "logvar_fc", x)

@@ -41,18 +41,24 @@ def _graphs_enabled() -> bool:
 
 
 class _GraphCache:
-    """key -> (CUDAGraph, static inputs, static outputs).  Everything a captured graph points at
-    (handle workspace, sigma table, static tensors) must stay put; owners call clear() when any of
-    it may move."""
+    """key -> (CUDAGraph, static inputs, static outputs, workspace generation).  Everything a captured graph points at
+    (handle workspace, sigma table, static tensors) must stay put.  The library may reallocate its workspace inside ANY
+    call (a larger batch through denoise / encode_cond / forward), so every replay first compares the handle's
+    workspace generation (rald_*_workspace_generation) with the one recorded after capture and re-captures on a
+    mismatch; owners additionally call clear() when something on the Python side changes."""
 
-    def __init__(self):
+    def __init__(self, generation=lambda: 0):
         self.entries: Dict[tuple, tuple] = {}
+        self.generation = generation
 
     def clear(self):
         self.entries.clear()
 
     def run(self, key, inputs, make_outputs, fn):
         ent = self.entries.get(key)
+        if ent is not None and ent[3] != self.generation():      # the workspace moved since capture: the graph is stale
+            del self.entries[key]
+            ent = None
         if ent is None:
             static_in = [t.clone() for t in inputs]
             side = torch.cuda.Stream()
@@ -66,9 +72,9 @@ class _GraphCache:
             with torch.cuda.graph(g):
                 outs = make_outputs()
                 fn(static_in, outs)
-            ent = (g, static_in, outs)
+            ent = (g, static_in, outs, self.generation())
             self.entries[key] = ent
-        g, static_in, outs = ent
+        g, static_in, outs, _ = ent
         for dst, src in zip(static_in, inputs):
             dst.copy_(src, non_blocking=True)
         g.replay()
@@ -82,7 +88,7 @@ class DitHandle:
         self.cfg = cfg
         self._h = C.c_void_p()
         check(lib().rald_dit_create(C.byref(cfg), C.byref(self._h)))
-        self._graphs = _GraphCache()
+        self._graphs = _GraphCache(lambda: lib().rald_dit_workspace_generation(self._h))
         self._reserved = 0
         self._sched = None
 
@@ -263,7 +269,7 @@ class AeHandle:
         self.cfg = cfg
         self._h = C.c_void_p()
         check(lib().rald_ae_create(C.byref(cfg), C.byref(self._h)))
-        self._graphs = _GraphCache()
+        self._graphs = _GraphCache(lambda: lib().rald_ae_workspace_generation(self._h))
         self._dec_batch = 0
 
     def __del__(self):

@@ -29,7 +29,7 @@ class DitConfig(C.Structure):
 
 class AeConfig(C.Structure):
     _fields_ = [("dim", c_int), ("num_latents", c_int), ("latent_dim", c_int), ("depth", c_int),
-                ("heads", c_int), ("dim_head", c_int), ("num_inputs", c_int)]
+                ("heads", c_int), ("dim_head", c_int), ("num_inputs", c_int), ("query_type", c_int)]
 
 
 # name -> (restype, argtypes); everything include/rald_hip.h declares
@@ -42,6 +42,8 @@ SIGNATURES = {
     "rald_dit_load_weight": (c_int, [c_void_p, c_char_p, c_void_p, c_i64]),
     "rald_dit_finalize": (c_int, [c_void_p]),
     "rald_dit_reserve": (c_int, [c_void_p, c_int]),
+    "rald_dit_workspace_generation": (c_i64, [c_void_p]),
+    "rald_ae_workspace_generation": (c_i64, [c_void_p]),
     "rald_dit_set_sigmas": (c_int, [c_void_p, c_float_p, c_int, c_void_p]),
     "rald_dit_cond_cache_bytes": (c_i64, [c_void_p, c_int]),
     "rald_dit_encode_cond_tokens": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),

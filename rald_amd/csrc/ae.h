@@ -25,6 +25,7 @@ struct Ae {
     std::vector<float> h_dec_wq, h_dec_wkv, h_dec_wo, h_dec_bo, h_out_w, h_out_b;
     std::set<std::string> expected, loaded;
     bool finalized = false;
+    int64_t ws_generation = 0;   // bumped by every workspace reallocation (captured hipGraphs point into the workspace)
     // encode workspace
     int enc_batch = 0;
     bf16 *e_feat = nullptr, *e_emb16 = nullptr, *e_embn16 = nullptr, *e_k = nullptr, *e_vt = nullptr, *e_o = nullptr, *e_xq = nullptr,

@@ -36,6 +36,8 @@ int Ae::create() {
     RALD_CHECK(c.latent_dim >= 1 && c.latent_dim <= 64 && (2 * c.latent_dim) % 4 == 0, "ae: latent_dim must be in [2,64] and even");
     RALD_CHECK(c.depth >= 1 && c.depth <= 256, "ae: bad depth");
     RALD_CHECK(c.num_inputs >= 32, "ae: num_inputs too small");
+    RALD_CHECK(c.query_type == 0 || c.query_type == 1, "ae: query_type must be 0 ('mix') or 1 ('learnable'); 'point' needs torch_cluster.fps");
+    const bool mixq = c.query_type == 0;
     const int M = c.num_latents, L = c.latent_dim;
     auto B16 = [&](size_t n) { return (bf16*)arena.alloc(n * 2, true); };
     auto F32 = [&](size_t n) { return (float*)arena.alloc(n * 4, true); };
@@ -53,7 +55,7 @@ int Ae::create() {
     };
     mk_attn(cross, d, true);
     mk_ff(cross_ff);
-    mk_attn(mix, I, false);
+    if (mixq) mk_attn(mix, I, false);
     mk_attn(dec, d, true);
     layers.resize(c.depth);
     for (auto& l : layers) {
@@ -62,10 +64,12 @@ int Ae::create() {
         l.ng = F32(d); l.nb = F32(d);
         mk_ff(l.ff);
     }
-    s_lat = F32((size_t)M * d);
-    d_lat = F32((size_t)M * d);
-    q1 = B16((size_t)M * I);
-    w_qp = B16((size_t)d * d); b_qp = F32(d);
+    s_lat = F32((size_t)M * d);                       // 'learnable': latents.weight
+    if (mixq) {
+        d_lat = F32((size_t)M * d);
+        q1 = B16((size_t)M * I);
+        w_qp = B16((size_t)d * d); b_qp = F32(d);
+    }
     w_proj = F32((size_t)d * L); b_proj = F32(d);
     w_ml = B16((size_t)2 * L * d); b_ml = F32((size_t)2 * L);
     wq_dec_t = B16((size_t)d * d);
@@ -88,11 +92,15 @@ int Ae::create() {
     };
     add_attn("cross_attend_blocks.0.", true);
     add_ff("cross_attend_blocks.1.");
-    for (const char* n : {"point_embed.basis", "point_embed.mlp.weight", "point_embed.mlp.bias", "s_latents.weight", "d_latents.weight",
-                          "query_proj.weight", "query_proj.bias", "to_outputs.weight", "to_outputs.bias", "proj.weight", "proj.bias",
-                          "mean_fc.weight", "mean_fc.bias", "logvar_fc.weight", "logvar_fc.bias"})
+    for (const char* n : {"point_embed.basis", "point_embed.mlp.weight", "point_embed.mlp.bias", "to_outputs.weight", "to_outputs.bias",
+                          "proj.weight", "proj.bias", "mean_fc.weight", "mean_fc.bias", "logvar_fc.weight", "logvar_fc.bias"})
         expected.insert(n);
-    add_attn("mix_attn_layer.", false);
+    if (mixq) {
+        for (const char* n : {"s_latents.weight", "d_latents.weight", "query_proj.weight", "query_proj.bias"}) expected.insert(n);
+        add_attn("mix_attn_layer.", false);
+    } else {
+        expected.insert("latents.weight");
+    }
     add_attn("decoder_cross_attn.", true);
     for (int i = 0; i < c.depth; ++i) {
         snprintf(buf, sizeof(buf), "layers.%d.0.", i); add_attn(buf, false);
@@ -183,7 +191,7 @@ int Ae::load_weight(const std::string& name, const float* data, int64_t nelem) {
         if (name == "point_embed.basis") { RALD_TRY(need(72)); rc = stager.to_f32(data, basis, 1, 72, 72, nullptr); }
         else if (name == "point_embed.mlp.weight") { RALD_TRY(need((int64_t)d * 51)); rc = stager.to_bf16(data, w_pe, d, 51, 64, nullptr); }
         else if (name == "point_embed.mlp.bias") { RALD_TRY(need(d)); rc = stager.to_f32(data, b_pe, 1, d, d, nullptr); }
-        else if (name == "s_latents.weight") { RALD_TRY(need((int64_t)M * d)); rc = stager.to_f32(data, s_lat, M, d, d, nullptr); }
+        else if (name == "s_latents.weight" || name == "latents.weight") { RALD_TRY(need((int64_t)M * d)); rc = stager.to_f32(data, s_lat, M, d, d, nullptr); }
         else if (name == "d_latents.weight") { RALD_TRY(need((int64_t)M * d)); rc = stager.to_f32(data, d_lat, M, d, d, nullptr); }
         else if (name == "query_proj.weight") { RALD_TRY(need((int64_t)d * d)); rc = stager.to_bf16(data, w_qp, d, d, d, nullptr); }
         else if (name == "query_proj.bias") { RALD_TRY(need(d)); rc = stager.to_f32(data, b_qp, 1, d, d, nullptr); }
@@ -208,14 +216,16 @@ int Ae::finalize() {
     for (const auto& k : expected) RALD_CHECK(loaded.count(k), "ae: missing key '" + k + "' (strict load)");
     const int M = cfg.num_latents;
     // (1) the mix layer's query is input-independent: q1 = to_q(LN(d_latents))      (:383-384)
-    bf16* tmp = (bf16*)arena.alloc((size_t)M * d * 2, true);
-    RALD_CHECK(tmp, "ae: allocation failed");
-    RALD_TRY(layernorm_mod(d_lat, tmp, M, d, mix.ng, mix.nb, 0, 1 << 30, 0.f, 1e-5f, nullptr));
-    GemmArgs g = gemm_args(tmp, d, mix.w_q, d, q1, I, nullptr, M, I, d);
-    g.alpha = (1.0f / sqrtf((float)cfg.dim_head)) * 1.4426950408889634f;     // q1 carries the softmax scale * log2(e)
-    RALD_TRY(gemm_nt(g, EPI_BF16, nullptr));
-    RALD_HIP(hipDeviceSynchronize());
-    arena.release(tmp);
+    if (cfg.query_type == 0) {
+        bf16* tmp = (bf16*)arena.alloc((size_t)M * d * 2, true);
+        RALD_CHECK(tmp, "ae: allocation failed");
+        RALD_TRY(layernorm_mod(d_lat, tmp, M, d, mix.ng, mix.nb, 0, 1 << 30, 0.f, 1e-5f, nullptr));
+        GemmArgs g = gemm_args(tmp, d, mix.w_q, d, q1, I, nullptr, M, I, d);
+        g.alpha = (1.0f / sqrtf((float)cfg.dim_head)) * 1.4426950408889634f;     // q1 carries the softmax scale * log2(e)
+        RALD_TRY(gemm_nt(g, EPI_BF16, nullptr));
+        RALD_HIP(hipDeviceSynchronize());
+        arena.release(tmp);
+    }
     // (2) decoder folding, in double on the host:
     //     wo' = Wo^T.w_out [d];  w_fold = Wv^T.wo' [d];  c0 = b_o.w_out + b_out;  WqT for G = K.Wq
     RALD_CHECK((int64_t)h_dec_wq.size() == (int64_t)d * d && (int64_t)h_dec_wkv.size() == (int64_t)2 * d * d &&
@@ -246,6 +256,7 @@ int Ae::finalize() {
 int Ae::reserve_encode(int B) {
     if (B <= enc_batch) return 0;
     RALD_HIP(hipDeviceSynchronize());
+    ++ws_generation;
     for (void** p : enc_ptrs()) if (*p) { arena.release(*p); *p = nullptr; }
     const size_t P = cfg.num_inputs, Pp = round_up(P, 64), M = cfg.num_latents, L = cfg.latent_dim;
     const size_t b = B;
@@ -282,28 +293,34 @@ int Ae::encode(const float* pc, int B, const float* eps, float* mean_o, float* l
     GemmArgs pe = gemm_args(e_feat, 64, w_pe, 64, e_emb32, d, b_pe, B * P, d, 64);
     RALD_TRY(gemm_nt(pe, EPI_F32, st));
     RALD_TRY(cast_f32_bf16(e_emb32, e_emb16, (int64_t)B * P * d, st));
-    // ---- mix query: dynamic_query = mix_attn_layer(d_latents, context=pc_embeddings) (:384; context NOT normed)
-    GemmArgs k1 = gemm_args(e_emb16, d, mix.w_k, d, e_k, I, nullptr, P, I, d);
-    k1.batch = B; k1.strideA = (int64_t)P * d; k1.strideC = (int64_t)Pp * I;
-    RALD_TRY(gemm_nt(k1, EPI_BF16, st));
-    GemmArgs v1 = gemm_args(mix.w_v, d, e_emb16, d, e_vt, Pp, nullptr, I, P, d);
-    v1.batch = B; v1.strideB = (int64_t)P * d; v1.strideC = (int64_t)I * Pp;
-    RALD_TRY(gemm_nt(v1, EPI_BF16, st));
-    AttnArgs a1;
-    a1.Q = q1; a1.ldq = I; a1.strideQ = 0;
-    a1.K = e_k; a1.ldk = I; a1.strideK = (int64_t)Pp * I;
-    a1.Vt = e_vt; a1.ldvt = Pp; a1.strideVt = (int64_t)I * Pp;
-    a1.O = e_o; a1.ldo = I; a1.strideO = (int64_t)M * I;
-    a1.nq = M; a1.nk = P; a1.k_rows = Pp; a1.heads = cfg.heads; a1.batch = B; a1.scale = 1.0f / sqrtf((float)cfg.dim_head); a1.q_prescaled = 1;
-    a1.ksplit = attention_pick_ksplit(M, P, cfg.heads, B);            // 512 queries x 10 000 keys: 32 workgroups at B = 1 without it
-    a1.part = e_part;
-    RALD_TRY(attention_d64(a1, st));
-    GemmArgs o1 = gemm_args(e_o, I, mix.w_o, I, e_dq, d, mix.b_o, BM, d, I);
-    RALD_TRY(gemm_nt(o1, EPI_F32, st));
-    // ---- x = query_proj(static_query + dynamic_query)                            (:385-386)
-    RALD_TRY(add_bcast_cast(s_lat, e_dq, e_xq, (int64_t)M * d, B, st));
-    GemmArgs qp = gemm_args(e_xq, d, w_qp, d, e_x, d, b_qp, BM, d, d);
-    RALD_TRY(gemm_nt(qp, EPI_F32, st));
+    if (cfg.query_type == 1) {
+        // ---- 'learnable' query (:378-379): x = latents.weight for every sample
+        for (int b = 0; b < B; ++b)
+            RALD_HIP(hipMemcpyAsync(e_x + (size_t)b * M * d, s_lat, (size_t)M * d * 4, hipMemcpyDeviceToDevice, st));
+    } else {
+        // ---- mix query: dynamic_query = mix_attn_layer(d_latents, context=pc_embeddings) (:384; context NOT normed)
+        GemmArgs k1 = gemm_args(e_emb16, d, mix.w_k, d, e_k, I, nullptr, P, I, d);
+        k1.batch = B; k1.strideA = (int64_t)P * d; k1.strideC = (int64_t)Pp * I;
+        RALD_TRY(gemm_nt(k1, EPI_BF16, st));
+        GemmArgs v1 = gemm_args(mix.w_v, d, e_emb16, d, e_vt, Pp, nullptr, I, P, d);
+        v1.batch = B; v1.strideB = (int64_t)P * d; v1.strideC = (int64_t)I * Pp;
+        RALD_TRY(gemm_nt(v1, EPI_BF16, st));
+        AttnArgs a1;
+        a1.Q = q1; a1.ldq = I; a1.strideQ = 0;
+        a1.K = e_k; a1.ldk = I; a1.strideK = (int64_t)Pp * I;
+        a1.Vt = e_vt; a1.ldvt = Pp; a1.strideVt = (int64_t)I * Pp;
+        a1.O = e_o; a1.ldo = I; a1.strideO = (int64_t)M * I;
+        a1.nq = M; a1.nk = P; a1.k_rows = Pp; a1.heads = cfg.heads; a1.batch = B; a1.scale = 1.0f / sqrtf((float)cfg.dim_head); a1.q_prescaled = 1;
+        a1.ksplit = attention_pick_ksplit(M, P, cfg.heads, B);            // 512 queries x 10 000 keys: 32 workgroups at B = 1 without it
+        a1.part = e_part;
+        RALD_TRY(attention_d64(a1, st));
+        GemmArgs o1 = gemm_args(e_o, I, mix.w_o, I, e_dq, d, mix.b_o, BM, d, I);
+        RALD_TRY(gemm_nt(o1, EPI_F32, st));
+        // ---- x = query_proj(static_query + dynamic_query)                            (:385-386)
+        RALD_TRY(add_bcast_cast(s_lat, e_dq, e_xq, (int64_t)M * d, B, st));
+        GemmArgs qp = gemm_args(e_xq, d, w_qp, d, e_x, d, b_qp, BM, d, d);
+        RALD_TRY(gemm_nt(qp, EPI_F32, st));
+    }
     // ---- x = cross_attn(x, context=pc_embeddings) + x   (1 head x dim, both normed) (:395)
     RALD_TRY(layernorm_mod(e_emb32, e_embn16, B * P, d, cross.cg, cross.cb, 0, 1 << 30, 0.f, 1e-5f, st));
     RALD_TRY(layernorm_mod(e_x, e_h, BM, d, cross.ng, cross.nb, 0, 1 << 30, 0.f, 1e-5f, st));
@@ -343,6 +360,7 @@ int Ae::encode(const float* pc, int B, const float* eps, float* mean_o, float* l
 int Ae::reserve_decode(int B) {
     if (B <= dec_batch) return 0;
     RALD_HIP(hipDeviceSynchronize());
+    ++ws_generation;
     for (void** p : dec_ptrs()) if (*p) { arena.release(*p); *p = nullptr; }
     const size_t M = cfg.num_latents, b = B;
     x_x = (float*)arena.alloc(b * M * d * 4, true);
@@ -436,6 +454,7 @@ int Ae::decode_latents(const float* z, int B, void* ctx, hipStream_t st) {
 int Ae::reserve_queries(int64_t rows) {
     if (rows <= q_rows) return 0;
     RALD_HIP(hipDeviceSynchronize());
+    ++ws_generation;
     for (void** p : qry_ptrs()) if (*p) { arena.release(*p); *p = nullptr; }
     const size_t M = cfg.num_latents, r = (size_t)rows;
     y_feat = (bf16*)arena.alloc(r * 64 * 2, true);

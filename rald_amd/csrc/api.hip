@@ -42,6 +42,7 @@ int rald_dit_reserve(rald_dit* h, int32_t max_batch) {
     RALD_CHECK(h && max_batch >= 1, "rald_dit_reserve: bad argument");
     return h->impl.reserve(max_batch);
 }
+int64_t rald_dit_workspace_generation(const rald_dit* h) { return h ? h->impl.ws_generation : -1; }
 int rald_dit_set_sigmas(rald_dit* h, const float* sigmas_host, int32_t n, void* stream) {
     RALD_CHECK(h && sigmas_host, "rald_dit_set_sigmas: null argument");
     return h->impl.set_sigmas(sigmas_host, n, (hipStream_t)stream);
@@ -101,6 +102,7 @@ int rald_ae_encode(rald_ae* h, const float* pc, int32_t batch, const float* eps,
     return h->impl.encode(pc, batch, eps, out_mean, out_logvar, out_z, out_kl, (hipStream_t)stream);
 }
 int64_t rald_ae_ctx_bytes(const rald_ae* h, int32_t batch) { return h ? h->impl.ctx_bytes(batch) : -1; }
+int64_t rald_ae_workspace_generation(const rald_ae* h) { return h ? h->impl.ws_generation : -1; }
 int rald_ae_decode_latents(rald_ae* h, const float* z, int32_t batch, void* ctx, void* stream) {
     RALD_CHECK(h, "null handle");
     return h->impl.decode_latents(z, batch, ctx, (hipStream_t)stream);

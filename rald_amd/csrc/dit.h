@@ -82,7 +82,9 @@ struct Dit {
     SigmaTable tables[2];
     int build_table(SigmaTable& t, const float* sig, int n, hipStream_t st);
     int64_t mod_row() const { return (int64_t)cfg.depth * 3 * 2 * D; }
-    // activation workspace
+    // activation workspace.  ws_generation counts every reallocation of a buffer that a captured hipGraph may point
+    // at (workspace, sigma tables): owners of captured graphs compare it with the value at capture time.
+    int64_t ws_generation = 0;
     int ws_batch = 0;
     float* ws_part = nullptr;   // split-K partial sums of the small-batch FF2 (norm.hip resid_splitk_ln)
     float *ws_x = nullptr, *ws_xcur = nullptr, *ws_xeul = nullptr, *ws_den = nullptr, *ws_dcur = nullptr;

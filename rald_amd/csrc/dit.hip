@@ -257,6 +257,7 @@ int Dit::finalize() {
 int Dit::reserve(int B) {
     if (B <= ws_batch) return 0;
     RALD_HIP(hipDeviceSynchronize());
+    ++ws_generation;
     for (void* p : {(void*)ws_h8, (void*)ws_hs, (void*)ws_g8, (void*)ws_gs, (void*)ws_part})
         if (p) arena.release(p);
     for (void* p : {(void*)ws_x, (void*)ws_h, (void*)ws_qk, (void*)ws_vt, (void*)ws_o, (void*)ws_q2, (void*)ws_g, (void*)ws_tok,
@@ -315,6 +316,7 @@ int Dit::build_table(SigmaTable& t, const float* sig, int n, hipStream_t st) {
     if (key == t.key) return 0;
     if (n > t.cap) {
         RALD_HIP(hipDeviceSynchronize());
+        ++ws_generation;
         for (void* p : {(void*)t.sigma, (void*)t.coef, (void*)t.cnoise, (void*)t.pe, (void*)t.temb0, (void*)t.temb, (void*)t.mod})
             if (p) arena.release(p);
         const int cap = n < 64 ? 64 : n;

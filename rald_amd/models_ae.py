@@ -4,9 +4,9 @@
 ``state_dict`` keys.  Arithmetic runs in librald_hip.so (include/rald_hip.h); no PyTorch compute
 path exists.
 
-Scope: query_type='mix' (the shipped config, configs/ae/*cone.yml:85) and 'learnable'-free;
-query_type='point' needs torch_cluster.fps (a CUDA extension that is neither vendored nor
-installed; SURVEY.md §8c 'parity unpinned') and raises.
+Scope: query_type='mix' (the shipped config, configs/ae/*cone.yml:85) and 'learnable' (:325-326,
+:378-379); query_type='point' needs torch_cluster.fps (a CUDA extension that is neither vendored
+nor installed; SURVEY.md §8c 'parity unpinned') and raises.
 """
 from __future__ import annotations
 
@@ -37,8 +37,8 @@ class KLAutoEncoder(_HipBacked):
     def __init__(self, *, depth=24, dim=512, queries_dim=512, output_dim=1, num_inputs=2048, num_latents=512,
                  latent_dim=64, heads=8, dim_head=64, weight_tie_layers=False, decoder_ff=False, query_type='point'):
         super().__init__()
-        if query_type != 'mix':
-            raise NotImplementedError(f"query_type={query_type!r}: only 'mix' (the shipped config) is built; "
+        if query_type not in ('mix', 'learnable'):
+            raise NotImplementedError(f"query_type={query_type!r}: 'mix' (the shipped config) and 'learnable' are built; "
                                       "'point' needs torch_cluster.fps")
         if weight_tie_layers or decoder_ff or output_dim != 1 or queries_dim != dim:
             raise NotImplementedError("only the create_autoencoder() configuration is built (models_ae.py:447-458)")
@@ -56,7 +56,8 @@ class KLAutoEncoder(_HipBacked):
         fp = self._state_fingerprint()
         if self._hip is None or self._hip_fp != fp:
             cfg = AeConfig(dim=self.dim, num_latents=self.num_latents, latent_dim=self.latent_dim, depth=self.depth,
-                           heads=self.heads, dim_head=self.dim_head, num_inputs=self.num_inputs)
+                           heads=self.heads, dim_head=self.dim_head, num_inputs=self.num_inputs,
+                           query_type={'mix': 0, 'learnable': 1}[self.query_type])
             h = AeHandle(cfg)
             h.load(self.state_dict().items())
             self._hip, self._hip_fp, self._ctx_memo = h, fp, None
@@ -72,13 +73,12 @@ class KLAutoEncoder(_HipBacked):
         return kl, z
 
     def _context(self, x):
-        """Latent stack + decoder context for latents x; memoised on the tensor identity, so the
-        reference's pattern of several decode() calls on the same latents (engine_generation.py
-        :204, :275, :300) runs the 24-layer stack once."""
-        key = (x.data_ptr(), x._version, tuple(x.shape))
-        if self._ctx_memo is None or self._ctx_memo[0] != key:
-            self._ctx_memo = (key, self._handle().decode_latents(x))
-        return self._ctx_memo[1]
+        """Latent stack + decoder context for latents x; memoised on the tensor OBJECT (+ its version; the entry keeps
+        the tensor alive, see _HipBacked._memo_hit), so the reference's pattern of several decode() calls on the same
+        `sampled_tokens` (engine_generation.py:204, :275, :300) runs the 24-layer stack once."""
+        if not self._memo_hit(self._ctx_memo, x):
+            self._ctx_memo = (x, x._version, self._handle().decode_latents(x))
+        return self._ctx_memo[2]
 
     def decode(self, x, queries):
         """x [B,M,latent_dim], queries [B,Q,3] -> logits [B,Q,1] (:408-424)."""
@@ -106,7 +106,7 @@ def create_autoencoder(dim=512, M=512, latent_dim=64, N=2048, determinisitc=Fals
                          latent_dim=latent_dim, heads=8, dim_head=64, query_type=query_type)
 
 
-# ---- factories (:461-512); only the 'mix' one is constructible (see module docstring) ----------
+# ---- factories (:461-512); the 'mix' and 'learnable' ones construct, the others need torch_cluster.fps (module docstring)
 def kl_d512_m512_l512(N=2048):
     return create_autoencoder(dim=512, M=512, latent_dim=512, N=N, determinisitc=False)
 

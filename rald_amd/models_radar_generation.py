@@ -28,9 +28,9 @@ from ._lib import DitConfig
 # ----------------------------------------------------------------------------------------------
 # parameter containers with the reference's key names
 # ----------------------------------------------------------------------------------------------
-def _init_param(name: str, shape) -> torch.Tensor:
-    """Fresh-module initialisation in the spirit of the reference's torch defaults: uniform
-    +-1/sqrt(fan_in) for weights and biases of Linear/Conv, ones/zeros for norms, N(0,1) for
+def _init_param(name: str, shape, fan_in=None) -> torch.Tensor:
+    """Fresh-module initialisation like the reference's torch defaults: Linear / Conv weights AND biases uniform
+    +-1/sqrt(fan_in) (`fan_in` of a bias = that of the weight it belongs to), ones/zeros for norms, N(0,1) for
     embeddings, and the zero-initialised proj_out (:198-201)."""
     if name.endswith("proj_out.weight") and "attn" not in name:
         return torch.zeros(shape)
@@ -39,16 +39,24 @@ def _init_param(name: str, shape) -> torch.Tensor:
     if len(shape) >= 2:
         bound = 1.0 / math.sqrt(int(np.prod(shape[1:])))
         return torch.empty(shape).uniform_(-bound, bound)
-    if ".norm" in name or name.startswith("norm"):
+    is_norm = any(seg.startswith("norm") for seg in name.split(".")[:-1]) and not name.endswith("linear.bias")
+    if is_norm:
         return torch.ones(shape) if name.endswith("weight") else torch.zeros(shape)
+    if name.endswith(".bias") and fan_in:
+        bound = 1.0 / math.sqrt(fan_in)
+        return torch.empty(shape).uniform_(-bound, bound)
     return torch.zeros(shape)
 
 
 def build_param_tree(root: nn.Module, spec, buffers=()) -> None:
     """Registers every (dotted name, shape) of `spec` under `root` as nested plain nn.Modules so
     that ``root.state_dict()`` has exactly the reference's keys, in the reference's order."""
+    spec = list(spec)
+    shapes = {n: tuple(sh) for n, sh in spec}
     for name, shape in spec:
         parts = name.split(".")
+        w = shapes.get(name[:-len("bias")] + "weight") if name.endswith(".bias") else None
+        fan_in = int(np.prod(w[1:])) if w is not None and len(w) >= 2 else None
         mod = root
         for p in parts[:-1]:
             if p not in mod._modules:
@@ -57,7 +65,7 @@ def build_param_tree(root: nn.Module, spec, buffers=()) -> None:
         if name in buffers:
             mod.register_buffer(parts[-1], _w.seeded_tensor(0, name, shape))
         else:
-            mod.register_parameter(parts[-1], nn.Parameter(_init_param(name, tuple(shape))))
+            mod.register_parameter(parts[-1], nn.Parameter(_init_param(name, tuple(shape), fan_in)))
 
 
 class _HipBacked(nn.Module):
@@ -85,6 +93,14 @@ class _HipBacked(nn.Module):
 
     def _device(self) -> torch.device:
         return next(self.parameters()).device
+
+    @staticmethod
+    def _memo_hit(memo, t: torch.Tensor) -> bool:
+        """A memo entry is (tensor, version, ...): it hits only for the SAME tensor object at the same version.  The
+        entry holds the tensor, so the object stays alive and `is` cannot match a later tensor that the caching
+        allocator placed at a recycled address (a (data_ptr, _version) key does: fresh `.to(device)` copies and
+        tensors the library wrote through data_ptr() all sit at version 0)."""
+        return memo is not None and memo[0] is t and memo[1] == t._version
 
 
 # ----------------------------------------------------------------------------------------------
@@ -255,14 +271,13 @@ class EDMPrecond(_HipBacked):
         return self._hip
 
     def _cond(self, cube: torch.Tensor, h: "DitHandle | None" = None):
-        """(tokens, cond cache) for a radar cube; memoised on the tensor identity so a caller that
+        """(tokens, cond cache) for a radar cube; memoised on the tensor OBJECT (+ its version) so a caller that
         invokes forward() in a loop with the same cube (the reference's sampler does, re-running
-        the 287-GFLOP encoder every NFE) encodes it once."""
-        key = (cube.data_ptr(), cube._version, tuple(cube.shape))
-        if self._cond_memo is None or self._cond_memo[0] != key:
+        the 287-GFLOP encoder every NFE) encodes it once.  See _memo_hit."""
+        if not self._memo_hit(self._cond_memo, cube):
             tokens, cache = (h or self._handle()).encode_cond(cube)      # (h: the caller already paid the 1.6 ms fingerprint walk)
-            self._cond_memo = (key, tokens, cache)
-        return self._cond_memo[1], self._cond_memo[2]
+            self._cond_memo = (cube, cube._version, tokens, cache)
+        return self._cond_memo[2], self._cond_memo[3]
 
     # -- reference API ------------------------------------------------------------------------
     def process_radar_cond(self, radar_cube):

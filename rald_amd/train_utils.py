@@ -108,6 +108,14 @@ class FlatAdamW:
             float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self.step_count,
             float(ema_rate if use_ema else 0.0), int(write_back_grads), C.c_void_p(_stream())))
         self._have_coef = False
+        self.mark_params_changed()
+
+    def mark_params_changed(self) -> None:
+        """The step rewrote every parameter through raw pointers into ``flat_p``; neither ``data_ptr()`` nor
+        ``_version`` of a ``p`` moved (``p.data = view`` keeps p's own version counter).  Bump the counters so that
+        everything keyed on them - the HIP handles' weight fingerprint (models_radar_generation._HipBacked),
+        autograd's saved-tensor checks - sees the new weights."""
+        torch._C._increment_version(self.params)
 
     def update_ema(self, rate: float = 0.99) -> None:
         """engine_generation.update_ema (:29-40) on the flat buffers (for iterations without a step)."""

@@ -241,6 +241,12 @@ def main():
         golden_optim()
     if "g13" in only:                      # ~1 min of CPU; not part of the default set
         golden_sample1000()
+    if want("g14"):
+        golden_chain()
+    if want("g15"):
+        golden_ae_learnable()
+    if want("g16"):
+        golden_edmloss_grad()
     print(f"done in {time.time() - t00:.0f}s")
 
 
@@ -407,6 +413,87 @@ def golden_sample1000():
         cond = O.process_radar_cond(sd, synth.radar_cube(1))
         s = O.edm_sampler(lambda xx, ss: O.edm_precond(sd, xx, ss, cond, depth=2), synth.latents([0]), num_steps=1000)
     save("g13_sample1000_oracle.npz", sample=s)
+
+
+def golden_chain():
+    """G14 (BASELINE config #4, engine_generation.py:195 -> :204/:275/:300 -> :229-232): the reference's own chain
+    radar cube -> EDMPrecond.sample -> KLAutoEncoder.decode -> logits (occupied iff > 0).
+      * full depth: the sampler output of G4 (EDMPrecond.sample as shipped, depth 24, B = 2; regenerating it bit for bit is
+        what `--only g3,g4` does) is decoded by the reference's kl_d512_m512_l32_mix on 4 096 seeded queries;
+      * three frames at batch 1 (the reference's eval_batch_size) through a depth-2 denoiser: different cubes, the SAME
+        sampler seed (batch_seeds=None -> seed 0 for every frame), so the frames differ only through the radar condition -
+        the vectors behind the test that frees frame k's tensors before frame k+1 is allocated.  The radar encoder is
+        hoisted out of the sampler loop here (bit-identical; as G1 does)."""
+    G, A, R = import_reference()
+    with torch.no_grad():
+        ae = A.kl_d512_m512_l32_mix(N=10000)
+        seed_module(ae, 0)
+        s18 = torch.from_numpy(np.load(os.path.join(HERE, "g4_sample18.npz"))["sample"])
+        q = synth.queries(2, 4096, seed=4243)
+        logits = ae.decode(s18, q).squeeze(-1)
+        m = G.EDMPrecond(n_latents=512, channels=32, depth=2, configs=CFG)
+        seed_module(m, 0)
+        raw_cond = m.process_radar_cond
+        frames, flogits = [], []
+        qf = synth.queries(1, 2048, seed=4244)
+        for cube_seed in (1234, 555, 909):
+            cube = synth.radar_cube(1, seed=cube_seed)
+            cond = raw_cond(cube)
+            m.process_radar_cond = lambda c, _cond=cond: _cond
+            s = m.sample(cond=cube, batch_seeds=None, cond_type="radar").to(torch.float32)
+            frames.append(s[0])
+            flogits.append(ae.decode(s, qf).squeeze(-1)[0])
+        save("g14_chain.npz", logits=logits, frame_samples=torch.stack(frames), frame_logits=torch.stack(flogits),
+             frame_cube_seeds=np.array([1234, 555, 909], np.int64))
+
+
+def golden_ae_learnable():
+    """G15: query_type='learnable' (models_ae.py:325-326, :378-379; factory kl_d512_m512_l32_learn): encode moments / z /
+    kl and decode logits, plus its state_dict key list."""
+    G, A, R = import_reference()
+    with torch.no_grad():
+        ae = A.create_autoencoder(dim=512, M=512, latent_dim=32, N=10000, query_type="learnable")
+        spec = seed_module(ae, 0)
+        path = os.path.join(HERE, "state_dict_keys.json")
+        keys = json.load(open(path))
+        keys["ae_learnable"] = spec
+        with open(path, "w") as f:
+            json.dump(keys, f)
+        pc = synth.point_cloud(2, 10000)
+        mean_hook, logvar_hook = {}, {}
+        h1 = ae.mean_fc.register_forward_hook(lambda m_, i, o: mean_hook.setdefault("v", o))
+        h2 = ae.logvar_fc.register_forward_hook(lambda m_, i, o: logvar_hook.setdefault("v", o))
+        torch.manual_seed(99)
+        kl, z = ae.encode(pc)
+        h1.remove(); h2.remove()
+        torch.manual_seed(99)
+        eps = torch.randn(2, 512, 32)
+        logits = ae.decode(z, synth.queries(2, 4096))
+        save("g15_ae_learnable.npz", kl=kl, z=z, eps=eps, mean=mean_hook["v"], logvar=logvar_hook["v"], logits=logits)
+
+
+def golden_edmloss_grad():
+    """G16 (the grad-norm SURVEY.md section 8c asks for beside G6): EDMLoss forward + backward through the depth-2
+    EDMPrecond WITH its jointly trained radar encoder (not hoisted: gradients flow through it), same model / inputs / seed
+    as G6; the total gradient norm (what clip_grad_norm_ returns, utils/misc.py:262) and the norms of the three parameter
+    groups."""
+    G, A, R = import_reference()
+    m = G.EDMPrecond(n_latents=512, channels=32, depth=2, configs=CFG)
+    seed_module(m, 0)
+    m.train()                      # the reference trains in train mode; dropout is 0 and drop_path 0, so eval == train here
+    cube = synth.radar_cube(2)
+    y = synth.normal([2, 512, 32], 21)
+    torch.manual_seed(5)
+    loss = G.EDMLoss()(m, y, cube, "radar")
+    loss.backward()
+    sq = {"model": 0.0, "radar_enc": 0.0, "tokeniser": 0.0}
+    for n, p in m.named_parameters():
+        g2 = float(p.grad.double().pow(2).sum()) if p.grad is not None else 0.0
+        key = "model" if n.startswith("model.") else ("radar_enc" if n.startswith("radar_enc.") else "tokeniser")
+        sq[key] += g2
+    total = float(np.sqrt(sum(sq.values())))
+    save("g16_edmloss_grad.npz", loss=loss.detach(), grad_norm=np.float64(total),
+         group_names=np.array(list(sq.keys())), group_norms=np.sqrt(np.array(list(sq.values()), np.float64)))
 
 
 if __name__ == "__main__":

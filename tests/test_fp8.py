@@ -108,9 +108,9 @@ def test_hip_gemm_mx8_rejects_bad_shapes():
 def test_fp8_qkv_mode_vs_reference_goldens():
     """BASELINE config #5: the denoiser with MXFP8 q/k/v projections (qkv_dtype='fp8') against the SAME
     fp32 goldens as the bf16 mode (SURVEY.md §8d 'fp8: same three numbers').  Stated tolerances for this mode:
-    one NFE D_x rel-L2 <= 1e-1 (measured 3.5e-2 / 3.0e-2 / 7e-5 at sigma 80 / 1 / 0.002), 18-step sampler
-    <= 1e-1 (measured 2.9e-2), raw F_x within 1.5e-1 of the bf16 mode (measured 6.5e-2 on these random
-    weights).  e4m3 keeps 3 mantissa bits: ~3.8 % per projection (test_hip_gemm_mx8_*), 72 fp8 projections per NFE."""
+    one NFE D_x rel-L2 <= 7e-2 (measured 3.5e-2 / 3.0e-2 / 7e-5 at sigma 80 / 1 / 0.002), 18-step sampler
+    <= 6e-2 (measured 2.9e-2) - bounds = 2x the measured values -, raw F_x within 1.3e-1 of the bf16 mode (measured
+    6.5e-2 on these random weights).  e4m3 keeps 3 mantissa bits: ~3.8 % per projection (test_hip_gemm_mx8_*), 72 fp8 projections per NFE."""
     from conftest import load_golden, rel_l2
     from rald_amd import config, models_radar_generation as G, weights
     m = G.LatentArrayTransformer(in_channels=32, t_channels=256, n_heads=8, d_head=64, depth=24)
@@ -121,7 +121,7 @@ def test_fp8_qkv_mode_vs_reference_goldens():
     m.qkv_dtype = "fp8"
     out8 = m(x, t, cond=cond)
     print("fp8 vs bf16 mode, raw F_x rel_l2:", rel_l2(out8, out16))
-    assert 1e-4 < rel_l2(out8, out16) < 1.5e-1                        # the mode really changes the arithmetic
+    assert 1e-4 < rel_l2(out8, out16) < 1.3e-1                        # the mode really changes the arithmetic
     edm = G.EDMPrecond(n_latents=512, channels=32, depth=24, configs=config.shipped_generation_config())
     edm.load_state_dict(weights.make_state_dict(weights.dit_spec(depth=24), 0), strict=True)
     edm = edm.cuda()
@@ -131,11 +131,11 @@ def test_fp8_qkv_mode_vs_reference_goldens():
     for s in (80.0, 1.0, 0.002):
         err = rel_l2(edm(x * max(s, 1.0), torch.tensor(s), cube, "radar"), g3[f"d_sigma_{s}"])
         print(f"fp8 mode, sigma {s}: D_x rel_l2 {err}")
-        assert err < 1e-1
+        assert err < 7e-2
     smp = edm.sample(cond=cube, batch_seeds=None, cond_type="radar")
     err = rel_l2(smp, g4["sample"])
     print("fp8 mode, 18-step sampler rel_l2", err)
-    assert err < 1e-1
+    assert err < 6e-2
     with pytest.raises(ValueError):
         m.qkv_dtype = "int4"
         m(x, t, cond=cond)
@@ -146,8 +146,9 @@ def test_fp8_qkv_mode_vs_reference_goldens():
 def test_fp8_ff_modes_vs_reference_goldens(mode):
     """qkv_dtype='fp8_ff1': MXFP8 q/k/v AND the GEGLU projection (its input, the norm3 output, also comes straight from the
     fused LayerNorm epilogue); 'fp8_ff': ff.net.2 as well (the GEGLU epilogue emits MXFP8, the fused residual+LayerNorm GEMM
-    consumes it; B >= 32 - below that it behaves like 'fp8_ff1').  Same goldens; stated tolerances: one NFE <= 1e-1,
-    18-step sampler <= 1e-1; a B = 32 NFE of 'fp8_ff' (the batch where its own kernels run) within 1e-1 of the bf16 mode."""
+    consumes it; B >= 32 - below that it behaves like 'fp8_ff1').  Same goldens; stated tolerances (2x the measured 4.6e-2 /
+    3.8e-2 / 1e-4 per NFE and 3.7e-2 after the sampler): one NFE <= 9e-2, 18-step sampler <= 7.5e-2; a B = 32 NFE of 'fp8_ff'
+    (the batch where its own kernels run) within 9.5e-2 of the bf16 mode (measured 4.7e-2)."""
     from conftest import load_golden, rel_l2
     from rald_amd import config, models_radar_generation as G, weights
     edm = G.EDMPrecond(n_latents=512, channels=32, depth=24, configs=config.shipped_generation_config())
@@ -159,17 +160,17 @@ def test_fp8_ff_modes_vs_reference_goldens(mode):
         edm.qkv_dtype = mode
         err = rel_l2(edm(xb, torch.tensor(1.0), cb, "radar"), ref)
         print("fp8_ff vs bf16 mode at B=32, D_x rel_l2", err)
-        assert 1e-4 < err < 1e-1
+        assert 1e-4 < err < 9.5e-2
     edm.qkv_dtype = mode
     g3, g4 = load_golden("g3_precond.npz"), load_golden("g4_sample18.npz")
     cube, x = synth.radar_cube(2).cuda(), synth.latents([0, 1]).cuda()
     for s in (80.0, 1.0, 0.002):
         err = rel_l2(edm(x * max(s, 1.0), torch.tensor(s), cube, "radar"), g3[f"d_sigma_{s}"])
         print(f"{mode} mode, sigma {s}: D_x rel_l2 {err}")
-        assert err < 1e-1
+        assert err < 9e-2
     err = rel_l2(edm.sample(cond=cube, batch_seeds=None, cond_type="radar"), g4["sample"])
     print(f"{mode} mode, 18-step sampler rel_l2", err)
-    assert err < 1e-1
+    assert err < 7.5e-2
 
 
 @pytest.mark.gpu
@@ -177,7 +178,7 @@ def test_config5_1000_step_sampler_graph_captured_fp8_vs_oracle():
     """BASELINE config #5 as written: 1000-step sampler (1999 NFE), hipGraph-captured denoise loop, MXFP8 q/k/v.  Depth-2
     model, B = 1, against the fixture the fp32 CPU oracle produced for the same seeded weights, cube and latents
     (tests/golden/g13_sample1000_oracle.npz; ~40 s of CPU, so precomputed).  Stated tolerance after 1999 compounding NFEs:
-    2e-2 in bf16 mode (measured 3.2e-3), 1e-1 in fp8 mode (measured 1.7e-2); graph replay must equal eager launches."""
+    1e-2 in bf16 mode (measured 3.2e-3), 4e-2 in fp8 mode (measured 1.7e-2); graph replay must equal eager launches."""
     import os
     from conftest import load_golden, rel_l2
     from rald_amd import config, models_radar_generation as G, weights
@@ -195,5 +196,5 @@ def test_config5_1000_step_sampler_graph_captured_fp8_vs_oracle():
         assert torch.equal(outs[(mode, "1")], outs[(mode, "0")])                 # captured graph == eager launches
         err = rel_l2(outs[(mode, "1")], ref)
         print(f"1000-step sampler ({mode} projections) vs fp32 oracle: rel_l2 {err}")
-        assert err < (2e-2 if mode == "bf16" else 1e-1)
+        assert err < (1e-2 if mode == "bf16" else 4e-2)
     os.environ.pop("RALD_GRAPH", None)

@@ -144,3 +144,54 @@ def test_g8_radar_autoencoder_encode_and_keys():
     cube = synth.radar_cube(2)
     z = O.radar_encoder(sd, cube.permute(0, 4, 1, 2, 3), prefix="encoder.").permute(0, 2, 3, 4, 1)
     assert rel_l2(z, g["z"]) < TOL
+
+
+def test_g14_chain_sample_then_decode():
+    """BASELINE config #4 as the reference chains it (engine_generation.py:195 -> :204 -> :229-232): the reference's
+    sampler output (G4) decoded by the reference's autoencoder, and three batch-1 frames through a depth-2 denoiser."""
+    g = load_golden("g14_chain.npz")
+    sd_ae = weights.make_state_dict(weights.ae_spec(), seed=0)
+    s18 = load_golden("g4_sample18.npz")["sample"]
+    logits = O.ae_decode(sd_ae, s18, synth.queries(2, 4096, seed=4243), depth=24).squeeze(-1)
+    assert rel_l2(logits, g["logits"]) < TOL
+    sd = weights.make_state_dict(weights.dit_spec(depth=2), seed=0)
+    qf = synth.queries(1, 2048, seed=4244)
+    for i, cs in enumerate(g["frame_cube_seeds"]):
+        s = O.dit_sample(sd, synth.radar_cube(1, seed=int(cs)), synth.latents([0]), depth=2)
+        assert rel_l2(s[0], g["frame_samples"][i]) < 1e-4
+        lg = O.ae_decode(sd_ae, s, qf, depth=24).squeeze(-1)[0]
+        assert rel_l2(lg, g["frame_logits"][i]) < 1e-4
+    # the frames really differ through the condition alone (same sampler seed)
+    assert rel_l2(g["frame_samples"][0], g["frame_samples"][1]) > 5e-2
+
+
+def test_g15_learnable_query_autoencoder_and_keys():
+    keys = json.load(open(os.path.join(GOLDEN, "state_dict_keys.json")))
+    spec = weights.ae_spec(query_type="learnable")
+    assert [[n, list(s)] for n, s in spec] == keys["ae_learnable"]
+    sd = weights.make_state_dict(spec, seed=0)
+    g = load_golden("g15_ae_learnable.npz")
+    kl, z, mean, logvar = O.ae_encode(sd, synth.point_cloud(2, 10000), g["eps"])
+    assert rel_l2(mean, g["mean"]) < TOL and rel_l2(logvar, g["logvar"]) < TOL
+    assert rel_l2(z, g["z"]) < TOL and rel_l2(kl, g["kl"]) < TOL
+    assert rel_l2(O.ae_decode(sd, g["z"], synth.queries(2, 4096), depth=24), g["logits"]) < TOL
+
+
+def test_g16_edm_loss_gradient_norm(sd_d2):
+    """EDMLoss forward + backward through denoiser AND radar encoder (autograd of the oracle) against the reference's
+    total gradient norm and the norms of its three parameter groups."""
+    g6, g = load_golden("g6_edmloss.npz"), load_golden("g16_edmloss_grad.npz")
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and k != "point_embed.basis") for k, v in sd_d2.items()}
+    with torch.enable_grad():
+        cond = O.process_radar_cond(sd, synth.radar_cube(2))
+        loss = O.edm_loss(sd, synth.normal([2, 512, 32], 21), cond, g6["rnd_normal"], g6["noise"], depth=2)
+        loss.backward()
+    assert abs(loss.item() - g["loss"].item()) < 1e-5 * abs(g["loss"].item())
+    sq = {"model": 0.0, "radar_enc": 0.0, "tokeniser": 0.0}
+    for n, v in sd.items():
+        if v.grad is not None:
+            sq["model" if n.startswith("model.") else ("radar_enc" if n.startswith("radar_enc.") else "tokeniser")] += float(v.grad.double().pow(2).sum())
+    total = sum(sq.values()) ** 0.5
+    assert abs(total - float(g["grad_norm"])) < 1e-4 * float(g["grad_norm"])
+    for name, ref in zip(g["group_names"], g["group_norms"]):
+        assert abs(sq[str(name)] ** 0.5 - float(ref)) < 1e-4 * float(ref) + 1e-7
