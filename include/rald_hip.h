@@ -305,6 +305,15 @@ int rald_op_im2col_t(const void* x_bf16, void* out_bf16, int32_t B, int32_t ID, 
                      int64_t m0, int32_t nchunk, void* stream);
 int rald_op_rowdot(const void* a_bf16, const void* b_bf16, int64_t M, int32_t C, float* out, void* stream);
 int rald_op_softmax_rows(const float* S, int64_t ld_s, void* P_bf16, int64_t ld_p, int32_t rows, int32_t n, void* stream);
+/* Streaming query decoder (KLAutoEncoder.decode :417-424; rald_amd/csrc/ae_decode.hip).  _tables: the weight-only tables
+ * it is built on, computed on the HOST in double from host tensors of decoder_cross_attn (to_q [d,d], k half of to_kv [d,d],
+ * norm weight / bias [d]), point_embed.mlp (weight [d,51], bias [d]) and the folded value vector [d]:
+ * t2aug_out [d][64] fp32, l_img_out [64][64] fp16 bits (no GPU needed: what the CPU tests check the folding with).
+ * _queries_nw: rald_ae_decode_queries with the waves per workgroup given (8, 12, 16; 0 = default) for tuning runs. */
+int rald_op_ae_decode_tables(int32_t dim, const float* wq, const float* wk, const float* norm_w, const float* norm_b, const float* wpe,
+                             const float* bpe, const float* wfold, float* t2aug_out, uint16_t* l_img_out);
+int rald_op_ae_decode_queries_nw(rald_ae* h, const void* ctx, const float* queries, int32_t batch, int64_t n_queries, float* out_logits,
+                                 int32_t waves_per_workgroup, void* stream);
 /* MXFP8 (OCP microscaling: e4m3 elements + one e8m0 scale per 32 consecutive K elements of a row), the
  * "fp8 MFMA QKV/proj path" of BASELINE config #5.  C = alpha * A . B^T + bias on
  * v_mfma_scale_f32_16x16x128_f8f6f4; epilogue 0 = bf16, 1 = f32, 2 = f32 residual accumulate.  K % 128 == 0;

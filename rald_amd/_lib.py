@@ -114,6 +114,8 @@ SIGNATURES = {
     "rald_op_im2col_t": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_int, c_void_p]),
     "rald_op_rowdot": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     "rald_op_softmax_rows": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_void_p]),
+    "rald_op_ae_decode_tables": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rald_op_ae_decode_queries_nw": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_void_p, c_int, c_void_p]),
     "rald_op_gemm_mx8": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_void_p, c_i64, c_i64,
                                  c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "rald_op_quantize_mx8": (c_int, [c_void_p, c_int, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p]),

@@ -8,7 +8,6 @@ struct Ae {
     rald_ae_config cfg;
     int d = 512;     // model dim
     int I = 512;     // heads*dim_head of the multi-head blocks
-    static constexpr int64_t QUERY_CHUNK = 131072;
     DeviceArena arena;
     Stager stager;
     struct AttnW { bf16 *w_q = nullptr, *w_k = nullptr, *w_v = nullptr, *w_o = nullptr; float *b_o = nullptr, *ng = nullptr, *nb = nullptr, *cg = nullptr, *cb = nullptr; };
@@ -19,7 +18,12 @@ struct Ae {
     std::vector<Layer> layers;
     float *basis = nullptr, *b_pe = nullptr, *s_lat = nullptr, *d_lat = nullptr, *b_qp = nullptr, *w_proj = nullptr, *b_proj = nullptr,
           *b_ml = nullptr, *w_fold = nullptr;
-    bf16 *w_pe = nullptr, *q1 = nullptr, *w_qp = nullptr, *w_ml = nullptr, *wq_dec_t = nullptr;
+    bf16 *w_pe = nullptr, *q1 = nullptr, *w_qp = nullptr, *w_ml = nullptr;
+    // streaming query decoder (ae_decode.hip): weight-only tables built at finalize()
+    float* t2aug = nullptr;            // [d][64] fp32: LN_ctx(x) . t2aug = per-latent score coefficients (slot order) | h0 | hb | u
+    unsigned short* l_img = nullptr;   // [64][64] fp16 image: |L.f~|^2 = variance of the query embedding
+    int basis_diag = 0;                // PointEmbed basis is the reference's block-diagonal one (models_ae.py:115-124)
+    std::vector<float> h_basis, h_wpe, h_bpe, h_dec_ng, h_dec_nb;
     int* d_geglu_map = nullptr;
     float c0 = 0.f;
     std::vector<float> h_dec_wq, h_dec_wkv, h_dec_wo, h_dec_bo, h_out_w, h_out_b;
@@ -39,15 +43,11 @@ struct Ae {
     // latent-stack workspace
     int dec_batch = 0;
     float *x_x = nullptr, *x_part = nullptr;   // x_part: split-K partial sums of the small-batch FF2 (norm.hip resid_splitk_ln)
-    bf16 *x_h = nullptr, *x_qk = nullptr, *x_vt = nullptr, *x_o = nullptr, *x_g = nullptr, *x_kd = nullptr;
+    bf16 *x_h = nullptr, *x_qk = nullptr, *x_vt = nullptr, *x_o = nullptr, *x_g = nullptr;
+    float* x_y = nullptr;                      // [B*M][64] fp32 context projection (ae_ctx_build)
     std::vector<void**> dec_ptrs() {
-        return {(void**)&x_x, (void**)&x_part, (void**)&x_h, (void**)&x_qk, (void**)&x_vt, (void**)&x_o, (void**)&x_g, (void**)&x_kd};
+        return {(void**)&x_x, (void**)&x_part, (void**)&x_h, (void**)&x_qk, (void**)&x_vt, (void**)&x_o, (void**)&x_g, (void**)&x_y};
     }
-    // query workspace (one chunk)
-    int64_t q_rows = 0;
-    bf16 *y_feat = nullptr, *y_qn = nullptr;
-    float *y_qe = nullptr, *y_s = nullptr;
-    std::vector<void**> qry_ptrs() { return {(void**)&y_feat, (void**)&y_qn, (void**)&y_qe, (void**)&y_s}; }
 
     int create();
     int load_attn(AttnW& a, int inner, const std::string& t, const float* data, int64_t nelem, bool* handled);
@@ -56,11 +56,10 @@ struct Ae {
     int finalize();
     int reserve_encode(int B);
     int reserve_decode(int B);
-    int reserve_queries(int64_t rows);
     int encode(const float* pc, int B, const float* eps, float* mean_o, float* logvar_o, float* z, float* kl, hipStream_t st);
     int64_t ctx_bytes(int B) const;
     int decode_latents(const float* z, int B, void* ctx, hipStream_t st);
-    int decode_queries(const void* ctx, const float* q, int B, int64_t Q, float* out, hipStream_t st);
+    int decode_queries(const void* ctx, const float* q, int B, int64_t Q, float* out, hipStream_t st, int nw = 0);
 };
 
 }  // namespace rald

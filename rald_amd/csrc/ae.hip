@@ -7,10 +7,10 @@
 //   decode_queries  :417-424   PointEmbed(queries) -> 1-head cross-attention over the latents -> Linear(dim,1)
 //
 // Decode is algebraically folded (exact in real arithmetic; the reference has no nonlinearity
-// between these Linears):  S = LN(qe).Wq^T.K^T = LN(qe).G^T with G = K.Wq per sample, and
-// to_outputs(to_out(P.V)) = P.u + c with u = LN_ctx(x).(Wv^T.Wo^T.w_out): per query one K=dim
-// GEMM row against G plus a softmax-weighted dot with u - 0.59 MFLOP instead of 2.15 MFLOP and
-// no [Q,dim] intermediate beyond the embedding.
+// between these Linears): to_outputs(to_out(P.V)) = P.u + c with u = LN_ctx(x).(Wv^T.Wo^T.w_out), and the
+// scores S = LN(PointEmbed(q)).Wq^T.K^T collapse onto the 51 Fourier features of the query (ae_decode.hip):
+// per sample a [M x 64] coefficient table, per query a K = 64 contraction + a softmax-weighted dot with u,
+// all inside ONE streaming kernel (12 B in, 4 B out per query).
 #include "ae.h"
 
 #include <cmath>
@@ -72,11 +72,12 @@ int Ae::create() {
     }
     w_proj = F32((size_t)d * L); b_proj = F32(d);
     w_ml = B16((size_t)2 * L * d); b_ml = F32((size_t)2 * L);
-    wq_dec_t = B16((size_t)d * d);
+    t2aug = F32((size_t)d * 64);
+    l_img = (unsigned short*)arena.alloc(64 * 64 * 2, true);
     w_fold = F32(d);
     std::vector<int> rm = geglu_rowmap(4 * d);
     d_geglu_map = (int*)arena.alloc(rm.size() * 4, false);
-    RALD_CHECK(d_geglu_map && w_fold && wq_dec_t, "ae: device allocation failed");
+    RALD_CHECK(d_geglu_map && w_fold && t2aug && l_img, "ae: device allocation failed");
     RALD_HIP(hipMemcpy(d_geglu_map, rm.data(), rm.size() * 4, hipMemcpyHostToDevice));
 
     expected.clear();
@@ -164,6 +165,8 @@ int Ae::load_weight(const std::string& name, const float* data, int64_t nelem) {
         if (t == "fn.to_kv.weight") RALD_TRY(fetch_host(h_dec_wkv, data, nelem));
         if (t == "fn.to_out.weight") RALD_TRY(fetch_host(h_dec_wo, data, nelem));
         if (t == "fn.to_out.bias") RALD_TRY(fetch_host(h_dec_bo, data, nelem));
+        if (t == "norm.weight") RALD_TRY(fetch_host(h_dec_ng, data, nelem));
+        if (t == "norm.bias") RALD_TRY(fetch_host(h_dec_nb, data, nelem));
         rc = load_attn(dec, d, t, data, nelem, &handled);
     } else if (sscanf(name.c_str(), "layers.%d.%d.%127s", &li, &sub, tail) == 3) {
         RALD_CHECK(li >= 0 && li < cfg.depth && (sub == 0 || sub == 1), "ae: bad layer index in '" + name + "'");
@@ -188,9 +191,9 @@ int Ae::load_weight(const std::string& name, const float* data, int64_t nelem) {
         }
     } else {
         handled = true;
-        if (name == "point_embed.basis") { RALD_TRY(need(72)); rc = stager.to_f32(data, basis, 1, 72, 72, nullptr); }
-        else if (name == "point_embed.mlp.weight") { RALD_TRY(need((int64_t)d * 51)); rc = stager.to_bf16(data, w_pe, d, 51, 64, nullptr); }
-        else if (name == "point_embed.mlp.bias") { RALD_TRY(need(d)); rc = stager.to_f32(data, b_pe, 1, d, d, nullptr); }
+        if (name == "point_embed.basis") { RALD_TRY(need(72)); RALD_TRY(fetch_host(h_basis, data, nelem)); rc = stager.to_f32(data, basis, 1, 72, 72, nullptr); }
+        else if (name == "point_embed.mlp.weight") { RALD_TRY(need((int64_t)d * 51)); RALD_TRY(fetch_host(h_wpe, data, nelem)); rc = stager.to_bf16(data, w_pe, d, 51, 64, nullptr); }
+        else if (name == "point_embed.mlp.bias") { RALD_TRY(need(d)); RALD_TRY(fetch_host(h_bpe, data, nelem)); rc = stager.to_f32(data, b_pe, 1, d, d, nullptr); }
         else if (name == "s_latents.weight" || name == "latents.weight") { RALD_TRY(need((int64_t)M * d)); rc = stager.to_f32(data, s_lat, M, d, d, nullptr); }
         else if (name == "d_latents.weight") { RALD_TRY(need((int64_t)M * d)); rc = stager.to_f32(data, d_lat, M, d, d, nullptr); }
         else if (name == "query_proj.weight") { RALD_TRY(need((int64_t)d * d)); rc = stager.to_bf16(data, w_qp, d, d, d, nullptr); }
@@ -245,10 +248,18 @@ int Ae::finalize() {
     for (int i = 0; i < d; ++i) c += (double)h_dec_bo[i] * h_out_w[i];
     c0 = (float)c;
     RALD_HIP(hipMemcpy(w_fold, wf.data(), (size_t)d * 4, hipMemcpyHostToDevice));
-    std::vector<float> wqt((size_t)d * d);
-    for (int j = 0; j < d; ++j)
-        for (int cc = 0; cc < d; ++cc) wqt[(size_t)cc * d + j] = h_dec_wq[(size_t)j * d + cc];
-    RALD_TRY(stager.to_bf16(wqt.data(), wq_dec_t, d, d, d, nullptr));
+    // (3) the streaming query decoder's weight-only tables (ae_decode.hip): score coefficients and the variance factor
+    RALD_CHECK((int)h_dec_ng.size() == d && (int)h_dec_nb.size() == d && (int64_t)h_wpe.size() == (int64_t)d * 51 && (int)h_bpe.size() == d &&
+               h_basis.size() == 72, "ae: decoder tensors missing for the query-decode tables");
+    std::vector<float> t2;
+    std::vector<unsigned short> limg;
+    RALD_TRY(ae_decode_tables(d, h_dec_wq.data(), h_dec_wkv.data(), h_dec_ng.data(), h_dec_nb.data(), h_wpe.data(), h_bpe.data(), wf.data(), t2, limg));
+    RALD_HIP(hipMemcpy(t2aug, t2.data(), t2.size() * 4, hipMemcpyHostToDevice));
+    RALD_HIP(hipMemcpy(l_img, limg.data(), limg.size() * 2, hipMemcpyHostToDevice));
+    basis_diag = 1;                    // block-diagonal basis (x -> columns 0-7, y -> 8-15, z -> 16-23): one multiply per projection
+    for (int a = 0; a < 3; ++a)
+        for (int e = 0; e < 24; ++e)
+            if (e / 8 != a && h_basis[(size_t)a * 24 + e] != 0.f) basis_diag = 0;
     finalized = true;
     return 0;
 }
@@ -370,15 +381,15 @@ int Ae::reserve_decode(int B) {
     x_vt = (bf16*)arena.alloc(b * I * M * 2, true);
     x_o = (bf16*)arena.alloc(b * M * I * 2, true);
     x_g = (bf16*)arena.alloc(b * M * 4 * d * 2, true);
-    x_kd = (bf16*)arena.alloc(b * M * d * 2, true);
+    x_y = (float*)arena.alloc(b * M * 64 * 4, true);
     for (void** p : dec_ptrs()) RALD_CHECK(*p, "ae: decode workspace allocation failed");
     dec_batch = B;
     return 0;
 }
 
 int64_t Ae::ctx_bytes(int B) const {
-    // G [B][M][d] bf16 + u [B][M] f32
-    return (int64_t)B * cfg.num_latents * d * 2 + (int64_t)B * cfg.num_latents * 4;
+    // per sample: fp16 coefficient image [M][64] + u [M] f32 + the image's scale (ae_decode.hip)
+    return (int64_t)B * ae_ctx_stride(cfg.num_latents);
 }
 
 int Ae::decode_latents(const float* z, int B, void* ctx, hipStream_t st) {
@@ -440,58 +451,17 @@ int Ae::decode_latents(const float* z, int B, void* ctx, hipStream_t st) {
         const float* nb = (li + 1 < layers.size()) ? layers[li + 1].nb : dec.cb;
         RALD_TRY(resid_ln(x_g, 4 * d, l.ff.w2, 4 * d, l.ff.b2, 4 * d, ng, nb));
     }
-    // decoder context: K = to_k(LN_ctx(x)) (LN_ctx(x) is in x_h); G = K.Wq (per sample); u = LN_ctx(x).w_fold
-    bf16* G = (bf16*)ctx;
-    float* u = (float*)((char*)ctx + (size_t)B * M * d * 2);
-    GemmArgs kd = gemm_args(x_h, d, dec.w_k, d, x_kd, d, nullptr, BM, d, d);
-    RALD_TRY(gemm_nt(kd, EPI_BF16, st));
-    GemmArgs gg = gemm_args(x_kd, d, wq_dec_t, d, G, d, nullptr, BM, d, d);
-    RALD_TRY(gemm_nt(gg, EPI_BF16, st));
-    RALD_TRY(ln_dot(x_x, dec.cg, dec.cb, w_fold, u, BM, d, st));
+    // decoder context (ae_decode.hip): LN_ctx(x) . t2aug -> per-latent score coefficients, h0, hb, u; one fp16 image per sample.
+    // (x_h holds LN_ctx(x) in bf16 from the last epilogue; the context is projected from the fp32 residual stream instead.)
+    RALD_TRY(ae_ctx_build(x_x, dec.cg, dec.cb, t2aug, x_y, ctx, B, M, d, st));
     return 0;
 }
 
-int Ae::reserve_queries(int64_t rows) {
-    if (rows <= q_rows) return 0;
-    RALD_HIP(hipDeviceSynchronize());
-    ++ws_generation;
-    for (void** p : qry_ptrs()) if (*p) { arena.release(*p); *p = nullptr; }
-    const size_t M = cfg.num_latents, r = (size_t)rows;
-    y_feat = (bf16*)arena.alloc(r * 64 * 2, true);
-    y_qe = (float*)arena.alloc(r * d * 4, true);
-    y_qn = (bf16*)arena.alloc(r * d * 2, true);
-    y_s = (float*)arena.alloc(r * M * 4, true);
-    for (void** p : qry_ptrs()) RALD_CHECK(*p, "ae: query workspace allocation failed");
-    q_rows = rows;
-    return 0;
-}
-
-int Ae::decode_queries(const void* ctx, const float* q, int B, int64_t Q, float* out, hipStream_t st) {
+int Ae::decode_queries(const void* ctx, const float* q, int B, int64_t Q, float* out, hipStream_t st, int nw) {
     RALD_CHECK(finalized, "ae: weights not finalized");
     RALD_CHECK(ctx && q && out && B >= 1 && Q >= 1, "ae: bad arguments");
-    const int M = cfg.num_latents;
-    const int64_t chunk = Q < QUERY_CHUNK ? Q : QUERY_CHUNK;
-    RALD_TRY(reserve_queries(chunk));
-    const bf16* G = (const bf16*)ctx;
-    const float* u = (const float*)((const char*)ctx + (size_t)B * M * d * 2);
-    const float scale = 1.0f / sqrtf((float)d);
-    for (int b = 0; b < B; ++b) {
-        for (int64_t off = 0; off < Q; off += chunk) {
-            const int n = (int)((Q - off) < chunk ? (Q - off) : chunk);
-            const float* qp = q + ((int64_t)b * Q + off) * 3;
-            RALD_TRY(point_features(qp, basis, y_feat, n, st));
-            GemmArgs pe = gemm_args(y_feat, 64, w_pe, 64, y_qe, d, b_pe, n, d, 64);
-            RALD_TRY(gemm_nt(pe, EPI_F32, st));
-            RALD_TRY(layernorm_mod(y_qe, y_qn, n, d, dec.ng, dec.nb, 0, 1 << 30, 0.f, 1e-5f, st));
-            GemmArgs s = gemm_args(y_qn, d, G + (size_t)b * M * d, d, y_s, M, nullptr, n, M, d);
-            s.alpha = scale;
-            RALD_TRY(gemm_nt(s, EPI_F32, st));
-            float* o = out + (int64_t)b * Q + off;
-            if (M == 256 || M == 512 || M == 1024) RALD_TRY(softmax_dot(y_s, u + (size_t)b * M, o, n, M, 1 << 30, c0, st));
-            else RALD_TRY(softmax_dot_generic(y_s, u + (size_t)b * M, o, n, M, 1 << 30, c0, st));
-        }
-    }
-    return 0;
+    RALD_CHECK((uintptr_t)ctx % 16 == 0, "ae: decoder context must be 16-byte aligned");
+    return ae_decode_stream(ctx, l_img, q, out, basis, basis_diag, B, Q, cfg.num_latents, c0, st, nw);
 }
 
 }  // namespace rald

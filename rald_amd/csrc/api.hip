@@ -1,5 +1,6 @@
 // extern "C" surface of librald_hip.so (include/rald_hip.h).  Thin: argument checks + dispatch.
 #include <cstdlib>
+#include <cstring>
 
 #include "ae.h"
 #include "dit.h"
@@ -111,6 +112,23 @@ int rald_ae_decode_queries(rald_ae* h, const void* ctx, const float* queries, in
                            float* out_logits, void* stream) {
     RALD_CHECK(h, "null handle");
     return h->impl.decode_queries(ctx, queries, batch, n_queries, out_logits, (hipStream_t)stream);
+}
+
+// tuning / test entry points of the streaming query decoder (ae_decode.hip)
+int rald_op_ae_decode_queries_nw(rald_ae* h, const void* ctx, const float* queries, int32_t batch, int64_t n_queries, float* out_logits,
+                                 int32_t waves_per_workgroup, void* stream) {
+    RALD_CHECK(h, "null handle");
+    return h->impl.decode_queries(ctx, queries, batch, n_queries, out_logits, (hipStream_t)stream, waves_per_workgroup);
+}
+int rald_op_ae_decode_tables(int32_t dim, const float* wq, const float* wk, const float* norm_w, const float* norm_b, const float* wpe,
+                             const float* bpe, const float* wfold, float* t2aug_out, uint16_t* l_img_out) {
+    RALD_CHECK(wq && wk && norm_w && norm_b && wpe && bpe && wfold && t2aug_out && l_img_out && dim >= 64, "rald_op_ae_decode_tables: bad argument");
+    std::vector<float> t2;
+    std::vector<unsigned short> li;
+    RALD_TRY(rald::ae_decode_tables(dim, wq, wk, norm_w, norm_b, wpe, bpe, wfold, t2, li));
+    memcpy(t2aug_out, t2.data(), t2.size() * 4);
+    memcpy(l_img_out, li.data(), li.size() * 2);
+    return 0;
 }
 
 // ---- standalone radar-spectrum encoder (RadarAutoencoder.encoder) -------------------------------

@@ -1,6 +1,7 @@
 // Internal launch interface of the kernel files (not part of the C-ABI; include/rald_hip.h is).
 #pragma once
 #include <cstdlib>
+#include <vector>
 
 #include "common.h"
 
@@ -122,6 +123,16 @@ int ln_dot(const float* x, const float* gamma, const float* beta, const float* w
 int add_bcast_cast(const float* a, const float* d, bf16* out, int64_t per_batch, int batch, hipStream_t st);
 int posterior(const float* ml, const float* eps, float* mean_o, float* logvar_o, float* z, float* kl, int B, int rows, int L, hipStream_t st);
 int small_k_linear(const float* in, const float* W, const float* bias, float* out, int M, int K, int N, hipStream_t st);
+
+// ---------------------------------------------------------------- ae_decode.hip (streaming query decoder)
+// per-sample decoder context: [ fp16 image M x 128 B | u: M floats | inv_scale + 3 pad floats ]
+inline int64_t ae_ctx_stride(int M) { return (int64_t)M * 128 + (int64_t)M * 4 + 16; }
+int ae_decode_tables(int d, const float* Wq, const float* Wk, const float* ng, const float* nb, const float* Wpe, const float* bpe,
+                     const float* wfold, std::vector<float>& t2aug, std::vector<unsigned short>& l_img);   // host, double precision
+int ae_ctx_build(const float* x, const float* gamma, const float* beta, const float* t2aug, float* Yscratch, void* ctx, int B, int M, int d,
+                 hipStream_t st);
+int ae_decode_stream(const void* ctx, const unsigned short* l_img, const float* queries, float* out, const float* basis, int basis_diag,
+                     int B, int64_t Q, int M, float c0, hipStream_t st, int nw = 0);
 
 // ---------------------------------------------------------------- post.hip
 int post_scratch_ints(int64_t Q);
