@@ -305,6 +305,19 @@ int rald_op_im2col_t(const void* x_bf16, void* out_bf16, int32_t B, int32_t ID, 
                      int64_t m0, int32_t nchunk, void* stream);
 int rald_op_rowdot(const void* a_bf16, const void* b_bf16, int64_t M, int32_t C, float* out, void* stream);
 int rald_op_softmax_rows(const float* S, int64_t ld_s, void* P_bf16, int64_t ld_p, int32_t rows, int32_t n, void* stream);
+/* Small-batch fused attention sub-blocks (rald_amd/csrc/attn_small.hip; CrossAttention :55-76 + the to_out Linear).
+ * _self_proj: qkv [batch*n_latents][ld] bf16 = q (pre-multiplied by scale*log2e) | k | v of a fused projection, 8 heads x 64;
+ *   part[h][row][512] = attention output of head h times Wo[:, 64h:64h+64]^T (fp32 partial of to_out).
+ * _q2_proj: h [M][512] bf16 -> to_q (Wq, scaled by qscale) -> attention over 64 cached condition tokens (Kc[b*strideK + key*ldk +
+ *   64h + d], Vt[b*strideVt + (64h + d)*ldvt + key]) -> part likewise.
+ * _reduce_resid_ln: x[M][512] += bias + sum_s part[s] (fixed order); h = LN(x)*(add_one + g) + b as bf16 when h is given. */
+int rald_op_attn_self_proj(const void* qkv_bf16, int64_t ld, const void* Wo_bf16, float* part, int32_t n_latents, int32_t heads, int32_t batch,
+                           void* stream);
+int rald_op_xattn_q2_proj(const void* h_bf16, const void* Wq_bf16, const void* Kc_bf16, int64_t ldk, int64_t strideK, const void* Vt_bf16,
+                          int64_t ldvt, int64_t strideVt, const void* Wo_bf16, float* part, int32_t M, int32_t n_latents, int32_t heads,
+                          int32_t n_keys, float qscale, void* stream);
+int rald_op_reduce_resid_ln(const float* part, int32_t slabs, int64_t slab_stride, const float* bias, float* x, void* h_bf16, int32_t M,
+                            const float* g, const float* b, int64_t gstride, int32_t rows_per_group, float add_one, float eps, void* stream);
 /* Streaming query decoder (KLAutoEncoder.decode :417-424; rald_amd/csrc/ae_decode.hip).  _tables: the weight-only tables
  * it is built on, computed on the HOST in double from host tensors of decoder_cross_attn (to_q [d,d], k half of to_kv [d,d],
  * norm weight / bias [d]), point_embed.mlp (weight [d,51], bias [d]) and the folded value vector [d]:

@@ -116,6 +116,11 @@ SIGNATURES = {
     "rald_op_softmax_rows": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_void_p]),
     "rald_op_ae_decode_tables": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rald_op_ae_decode_queries_nw": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_void_p, c_int, c_void_p]),
+    "rald_op_attn_self_proj": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "rald_op_xattn_q2_proj": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_int, c_int, c_int,
+                                      c_int, c_float, c_void_p]),
+    "rald_op_reduce_resid_ln": (c_int, [c_void_p, c_int, c_i64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_i64, c_int, c_float,
+                                        c_float, c_void_p]),
     "rald_op_gemm_mx8": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_void_p, c_i64, c_i64,
                                  c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "rald_op_quantize_mx8": (c_int, [c_void_p, c_int, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p]),

@@ -375,7 +375,10 @@ int Ae::reserve_decode(int B) {
     for (void** p : dec_ptrs()) if (*p) { arena.release(*p); *p = nullptr; }
     const size_t M = cfg.num_latents, b = B;
     x_x = (float*)arena.alloc(b * M * d * 4, true);
-    x_part = (float*)arena.alloc((size_t)4 * (b * M < splitk_max_rows() ? b * M : splitk_max_rows()) * 512 * 4, true);
+    {   // split-K partials of the small-batch FF2 (4 slabs) / per-head partials of the fused attention sub-block (heads slabs, <= 2048 rows)
+        const size_t rows = b * M, r4 = rows < (size_t)splitk_max_rows() ? rows : (size_t)splitk_max_rows(), r8 = rows < 2048 ? rows : 2048;
+        x_part = (float*)arena.alloc((4 * r4 > (size_t)cfg.heads * r8 ? 4 * r4 : (size_t)cfg.heads * r8) * 512 * 4, true);
+    }
     x_h = (bf16*)arena.alloc(b * M * d * 2, true);
     x_qk = (bf16*)arena.alloc(b * M * 3 * I * 2, true);       // q | k | v
     x_vt = (bf16*)arena.alloc(b * I * M * 2, true);
@@ -439,10 +442,16 @@ int Ae::decode_latents(const float* z, int B, void* ctx, hipStream_t st) {
             a.K = x_qk + I; a.ldk = 2 * I; a.strideK = (int64_t)M * 2 * I;
             a.Vt = x_vt; a.ldvt = M; a.strideVt = (int64_t)I * M;
         }
+        if (d == 512 && M % 64 == 0 && small_m_fused(BM, M, cfg.heads, I, 64)) {
+            // small batches: attention + per-head slice of to_out in one kernel, partials summed with the residual + the FF's PreNorm
+            RALD_TRY(attn_self_proj(x_qk, 3 * I, l.w_o, x_part, M, cfg.heads, B, st));
+            RALD_TRY(reduce_resid_ln(x_part, cfg.heads, (int64_t)BM * d, l.b_o, x_x, x_h, BM, l.ff.ng, l.ff.nb, 0, 1 << 30, 0.f, 1e-5f, st));
+        } else {
         a.O = x_o; a.ldo = I; a.strideO = (int64_t)M * I;
         a.nq = M; a.nk = M; a.k_rows = M; a.heads = cfg.heads; a.batch = B; a.scale = scale; a.q_prescaled = 1;
         RALD_TRY(attention_d64(a, st));
         RALD_TRY(resid_ln(x_o, I, l.w_o, I, l.b_o, I, l.ff.ng, l.ff.nb));             // + the FF's PreNorm
+        }
         // x = self_ff(x) + x                                                            (:414)
         GemmArgs f1 = gemm_args(x_h, d, l.ff.w1, d, x_g, 4 * d, l.ff.b1, BM, 8 * d, d);
         RALD_TRY(gemm_nt(f1, EPI_GEGLU, st));

@@ -417,6 +417,20 @@ int rald_op_attention_vrow(const void* Q, int64_t ldq, int64_t strideQ, const vo
     a.nq = nq; a.nk = nk; a.k_rows = nk; a.heads = heads; a.batch = batch; a.scale = scale; a.q_prescaled = 0;
     return attention_d64(a, (hipStream_t)stream);
 }
+int rald_op_attn_self_proj(const void* qkv_bf16, int64_t ld, const void* Wo_bf16, float* part, int32_t n_latents, int32_t heads, int32_t batch,
+                           void* stream) {
+    return attn_self_proj((const bf16*)qkv_bf16, ld, (const bf16*)Wo_bf16, part, n_latents, heads, batch, (hipStream_t)stream);
+}
+int rald_op_xattn_q2_proj(const void* h_bf16, const void* Wq_bf16, const void* Kc_bf16, int64_t ldk, int64_t strideK, const void* Vt_bf16,
+                          int64_t ldvt, int64_t strideVt, const void* Wo_bf16, float* part, int32_t M, int32_t n_latents, int32_t heads,
+                          int32_t n_keys, float qscale, void* stream) {
+    return xattn_q2_proj((const bf16*)h_bf16, (const bf16*)Wq_bf16, (const bf16*)Kc_bf16, ldk, strideK, (const bf16*)Vt_bf16, ldvt, strideVt,
+                         (const bf16*)Wo_bf16, part, M, n_latents, heads, n_keys, qscale, (hipStream_t)stream);
+}
+int rald_op_reduce_resid_ln(const float* part, int32_t slabs, int64_t slab_stride, const float* bias, float* x, void* h_bf16, int32_t M,
+                            const float* g, const float* b, int64_t gstride, int32_t rows_per_group, float add_one, float eps, void* stream) {
+    return reduce_resid_ln(part, slabs, slab_stride, bias, x, (bf16*)h_bf16, M, g, b, gstride, rows_per_group, add_one, eps, (hipStream_t)stream);
+}
 int rald_op_gemm_resid_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* x, void* h_bf16,
                           const float* g, const float* b, int64_t gstride, int32_t rows_per_group, float add_one, float eps,
                           int32_t M, int32_t K, void* stream) {

@@ -272,7 +272,14 @@ int Dit::reserve(int B) {
     ws_o = (bf16*)arena.alloc(M * D * 2, true);
     ws_q2 = (bf16*)arena.alloc(M * D * 2, true);
     ws_g = (bf16*)arena.alloc(M * 4 * D * 2, true);
-    ws_part = (float*)arena.alloc((size_t)4 * (M < splitk_max_rows() ? M : splitk_max_rows()) * 512 * 4, true);
+    // split-K partials of the small-batch FF2 (4 slabs of up to splitk_max_rows() rows) / per-head partials of the fused
+    // attention sub-blocks (n_heads slabs of up to 2048 rows, kernels.h small_m_fused)
+    {
+        const size_t r4 = M < (size_t)splitk_max_rows() ? M : (size_t)splitk_max_rows();
+        const size_t r8 = M < 2048 ? M : 2048;
+        const size_t slabs_rows = 4 * r4 > (size_t)cfg.n_heads * r8 ? 4 * r4 : (size_t)cfg.n_heads * r8;
+        ws_part = (float*)arena.alloc(slabs_rows * 512 * 4, true);
+    }
     ws_tok = (bf16*)arena.alloc((size_t)B * cfg.n_cond_tokens * cfg.context_dim * 2, true);
     ws_xcur = (float*)arena.alloc(nl * 4, true);
     ws_xeul = (float*)arena.alloc(nl * 4, true);
@@ -546,6 +553,16 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
             a1.K = ws_qk + D; a1.ldk = 2 * D; a1.strideK = (int64_t)NL * 2 * D;
             a1.Vt = ws_vt; a1.ldvt = NL; a1.strideVt = (int64_t)D * NL;
         }
+        if (vrow && small_m_fused(M, NL, cfg.n_heads, D, T)) {
+            // small batches (attn_small.hip): attention + that head's slice of to_out in one kernel per (head, 32-query block),
+            // the 8 per-head partials summed into the residual stream together with the next AdaLN; then to_q + the 64-key
+            // radar cross-attention + to_out slice likewise.  8 launches per block instead of 12.
+            RALD_TRY(attn_self_proj(ws_qk, 3 * D, l.w_o, ws_part, NL, cfg.n_heads, B, st));
+            RALD_TRY(reduce_resid_ln(ws_part, cfg.n_heads, (int64_t)M * D, l.b_o, ws_x, ws_h, M, m2, m2 + D, gstride, NL, 1.0f, 1e-5f, st));
+            RALD_TRY(xattn_q2_proj(ws_h, l.w_q2, Kc + (size_t)li * D, (int64_t)L * D, (int64_t)T * L * D, Vtc + (size_t)li * D * T, T, (int64_t)L * D * T,
+                                   l.w_o2, ws_part, M, NL, cfg.n_heads, T, qscale, st));
+            RALD_TRY(reduce_resid_ln(ws_part, cfg.n_heads, (int64_t)M * D, l.b_o2, ws_x, ws_h, M, m3, m3 + D, gstride, NL, 1.0f, 1e-5f, st));
+        } else {
         a1.O = ws_o; a1.ldo = D; a1.strideO = (int64_t)NL * D;
         a1.nq = NL; a1.nk = NL; a1.k_rows = NL; a1.heads = cfg.n_heads; a1.batch = B; a1.scale = scale; a1.q_prescaled = 1;
         RALD_TRY(attention_d64(a1, st));
@@ -562,6 +579,7 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
         a2.nq = NL; a2.nk = T; a2.k_rows = T; a2.heads = cfg.n_heads; a2.batch = B; a2.scale = scale; a2.q_prescaled = 1;
         RALD_TRY(attention_d64(a2, st));
         RALD_TRY(resid_ln(ws_o, D, l.w_o2, D, l.b_o2, D, m3));                     // + norm3
+        }
         // ---- x += ff(norm3(x, t))                                                   (:168)
         GemmArgs f1 = gemm_args(ws_h, D, l.w_ff1, D, ws_g, 4 * D, l.b_ff1, M, 8 * D, D);
         const bool timed = prof_on && prof_used + 2 <= (int)prof_ev.size();

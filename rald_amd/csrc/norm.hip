@@ -107,6 +107,16 @@ __global__ __launch_bounds__(256) void reduce_resid_ln_kernel(const float* __res
                  v[7] * rstd * (add_one + g1.w) + c1.w);
 }
 
+int reduce_resid_ln(const float* part, int S, int64_t part_stride, const float* bias, float* x, bf16* h, int M, const float* g, const float* b,
+                    int64_t gstride, int rows_per_group, float add_one, float eps, hipStream_t st) {
+    RALD_CHECK(part && bias && x && S >= 1 && S <= 64 && M >= 1, "reduce_resid_ln: bad arguments");
+    RALD_CHECK(!h || (g && b && rows_per_group > 0), "reduce_resid_ln: LayerNorm parameters missing");
+    hipLaunchKernelGGL(reduce_resid_ln_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, part, S, part_stride, bias, x, h, M, g, b, gstride, rows_per_group,
+                       add_one, eps);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
 // x[M][512] += A[M][K].W[512][K]^T + bias (K split over `splits` batch entries into `scratch` [splits][M][512] f32), then the LayerNorm
 int resid_splitk_ln(const bf16* A, int64_t lda, const bf16* W, int64_t ldw, const float* bias, float* x, bf16* h, const float* g, const float* b,
                     int64_t gstride, int rows_per_group, float add_one, float eps, int M, int K, int splits, float* scratch, hipStream_t st) {
@@ -121,10 +131,11 @@ int resid_splitk_ln(const bf16* A, int64_t lda, const bf16* W, int64_t ldw, cons
     return 0;
 }
 
-// ---- proj_in: K = C (latent channels, <= 64) is far too small for MFMA; fp32 FMA, 8 rows per WG.
-__global__ __launch_bounds__(256) void proj_in_kernel(const float* __restrict__ xin, const float* __restrict__ W,
-                                                      float* __restrict__ x, int M, int C, int D,
-                                                      const float* __restrict__ coef, int coef_stride, int rows_per_group) {
+// ---- proj_in: K = C (latent channels, <= 64) is far too small for MFMA and stays fp32.
+// Small M: 8 rows per workgroup, the weight read through L1/L2 (few workgroups, nothing to amortise a staging pass over).
+__global__ __launch_bounds__(256) void proj_in_small_kernel(const float* __restrict__ xin, const float* __restrict__ W,
+                                                            float* __restrict__ x, int M, int C, int D,
+                                                            const float* __restrict__ coef, int coef_stride, int rows_per_group) {
     __shared__ float sx[8][64];
     const int m0 = blockIdx.x * 8;
     for (int i = threadIdx.x; i < 8 * C; i += 256) {
@@ -147,11 +158,66 @@ __global__ __launch_bounds__(256) void proj_in_kernel(const float* __restrict__ 
             if (m0 + r < M) x[(int64_t)(m0 + r) * D + n] = acc[r];
     }
 }
+// Large M: 32 rows x 256 output columns per workgroup; that half of the weight sits in LDS as [n][C + 1] (odd row stride:
+// lane n reads its own row conflict-free; the small-M form reads it from global memory at a 128-byte lane stride, 64 cache
+// lines per load instruction - 45 us for the 67 MB x at B = 64), the input rows (pre-multiplied by c_in) as broadcasts.
+// Output rows leave fully coalesced.
+template <int C>
+__global__ __launch_bounds__(256) void proj_in_kernel(const float* __restrict__ xin, const float* __restrict__ W,
+                                                      float* __restrict__ x, int M, int D,
+                                                      const float* __restrict__ coef, int coef_stride, int rows_per_group) {
+    constexpr int R = 32, LDW = C + 1;
+    __shared__ float sw[256 * LDW];
+    __shared__ float sx[R * C];
+    const int m0 = blockIdx.x * R, n0 = blockIdx.y * 256;
+    for (int i = threadIdx.x; i < 256 * C; i += 256) sw[(i / C) * LDW + i % C] = W[(int64_t)n0 * C + i];
+    for (int i = threadIdx.x; i < R * C; i += 256) {
+        const int m = m0 + i / C;
+        sx[i] = m < M ? xin[(int64_t)m0 * C + i] * coef[(int64_t)(m / rows_per_group) * coef_stride + 0] : 0.f;
+    }
+    __syncthreads();
+    const int n = threadIdx.x;
+    const float* w = sw + n * LDW;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        float acc[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 4
+        for (int c = 0; c < C; ++c) {
+            const float wv = w[c];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = fmaf(sx[(16 * half + r) * C + c], wv, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + 16 * half + r;
+            if (m < M) x[(int64_t)m * D + n0 + n] = acc[r];
+        }
+    }
+}
 
+template <int C>
+static int launch_proj_in(const float* xin, const float* W, float* x, int M, int D, const float* coef, int coef_stride, int rows_per_group,
+                          hipStream_t st) {
+    hipLaunchKernelGGL(proj_in_kernel<C>, dim3(cdiv(M, 32), D / 256), dim3(256), 0, st, xin, W, x, M, D, coef, coef_stride, rows_per_group);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
 int proj_in(const float* xin, const float* W, float* x, int M, int C, int D, const float* coef,
             int coef_stride, int rows_per_group, hipStream_t st) {
     RALD_CHECK(C >= 1 && C <= 64, "proj_in: latent channels must be in [1,64]");
-    hipLaunchKernelGGL(proj_in_kernel, dim3(cdiv(M, 8)), dim3(256), 0, st, xin, W, x, M, C, D, coef, coef_stride, rows_per_group);
+    RALD_CHECK(D % 256 == 0, "proj_in: D must be a multiple of 256");
+    if (M > 4096) {
+        switch (C) {                                   // the reference's factories: 4, 8, 16, 32 latent channels
+            case 4: return launch_proj_in<4>(xin, W, x, M, D, coef, coef_stride, rows_per_group, st);
+            case 8: return launch_proj_in<8>(xin, W, x, M, D, coef, coef_stride, rows_per_group, st);
+            case 16: return launch_proj_in<16>(xin, W, x, M, D, coef, coef_stride, rows_per_group, st);
+            case 32: return launch_proj_in<32>(xin, W, x, M, D, coef, coef_stride, rows_per_group, st);
+            default: break;
+        }
+    }
+    hipLaunchKernelGGL(proj_in_small_kernel, dim3(cdiv(M, 8)), dim3(256), 0, st, xin, W, x, M, C, D, coef, coef_stride, rows_per_group);
     RALD_HIP(hipGetLastError());
     return 0;
 }
@@ -195,21 +261,37 @@ __global__ __launch_bounds__(256) void final_norm_proj_kernel(const float* __res
     }
     const float* cf = coef + (int64_t)(row / rows_per_group) * coef_stride;
     const float c_skip = cf[1], c_out = cf[2];
-    float mine = 0.f;                                   // lane c keeps output channel c
-    for (int c = 0; c < C; ++c) {
-        const float4* w = reinterpret_cast<const float4*>(Wout + (int64_t)c * D);
-        float p = 0.f;
+    // 32 output channels at a time: every lane forms its partial dot products for all 32, then a reduce-scatter over the
+    // lanes (xor 32, 16, 8, 4, 2 - each step halves the channels a lane still carries - and one last add over xor 1) leaves
+    // channel c0 + (lane >> 1) on the lane: 32 cross-lane adds per row instead of 32 full 6-step reductions (192).
+    for (int c0 = 0; c0 < C; c0 += 32) {
+        float p[32];
 #pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            float4 ww = w[lane + 64 * k];
-            p += v[k].x * ww.x + v[k].y * ww.y + v[k].z * ww.z + v[k].w * ww.w;
+        for (int c = 0; c < 32; ++c) {
+            const int cc = c0 + c < C ? c0 + c : C - 1;
+            const float4* w = reinterpret_cast<const float4*>(Wout + (int64_t)cc * D);
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const float4 ww = w[lane + 64 * k];
+                a += v[k].x * ww.x + v[k].y * ww.y + v[k].z * ww.z + v[k].w * ww.w;
+            }
+            p[c] = a;
         }
-        p = wave_sum(p);
-        if (lane == c) mine = p;
-    }
-    if (lane < C) {
-        const int64_t o = (int64_t)row * C + lane;
-        out[o] = c_skip * xin[o] + c_out * mine;
+#define RALD_RS_STEP(N, OFF)                                                                          \
+        _Pragma("unroll") for (int i = 0; i < N; ++i) {                                              \
+            const bool hi = (lane & OFF) != 0;                                                        \
+            const float keep = hi ? p[i + N] : p[i], send = hi ? p[i] : p[i + N];                     \
+            p[i] = keep + __shfl_xor(send, OFF, 64);                                                  \
+        }
+        RALD_RS_STEP(16, 32) RALD_RS_STEP(8, 16) RALD_RS_STEP(4, 8) RALD_RS_STEP(2, 4) RALD_RS_STEP(1, 2)
+#undef RALD_RS_STEP
+        const float tot = p[0] + __shfl_xor(p[0], 1, 64);
+        const int ch = c0 + (lane >> 1);
+        if ((lane & 1) == 0 && ch < C) {
+            const int64_t o = (int64_t)row * C + ch;
+            out[o] = c_skip * xin[o] + c_out * tot;
+        }
     }
 }
 

@@ -223,3 +223,81 @@ def test_gemm_residual_with_fused_layernorm(H, M, K):
     h = H.op_gemm_resid_ln(A, W, bias, x, mod, mod[:, 512:], gstride=1024, rows_per_group=rpg, add_one=1.0)
     assert rel_l2(x, xref) < 2e-6
     assert rel_l2(h, href) < 4e-3
+
+
+# ---- small-batch fused attention sub-blocks (attn_small.hip) ---------------------------------------------------------------
+def _c(t):
+    import ctypes as C
+    return C.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+@pytest.mark.parametrize("NL,B", [(512, 1), (512, 3), (256, 2)])
+def test_attn_self_proj_partials_vs_torch(NL, B):
+    """part[h] = softmax(q_h k_h^T) v_h . Wo[:, 64h:64h+64]^T per head; sum_h part[h] = to_out(attention) without bias."""
+    import ctypes as C
+    from rald_amd._lib import check, lib
+    g = torch.Generator("cpu").manual_seed(3)
+    D = 512
+    qkv = (torch.randn(B * NL, 3 * D, generator=g) * 0.8).cuda().bfloat16()
+    Wo = (torch.randn(D, D, generator=g) / 22).cuda().bfloat16()
+    part = torch.full((8, B * NL, D), float("nan"), device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib().rald_op_attn_self_proj(_c(qkv), 3 * D, _c(Wo), _c(part), NL, 8, B, C.c_void_p(st)))
+    f = qkv.float().view(B, NL, 3, 8, 64)
+    q, k, v = f[:, :, 0].permute(0, 2, 1, 3), f[:, :, 1].permute(0, 2, 1, 3), f[:, :, 2].permute(0, 2, 1, 3)    # [B,8,NL,64]
+    p = torch.softmax(q @ k.transpose(-1, -2) * math.log(2.0), dim=-1)            # q carries log2e: the kernel uses exp2
+    o = p @ v                                                                     # [B,8,NL,64]
+    ref = torch.stack([o[:, h].reshape(B * NL, 64) @ Wo.float()[:, 64 * h:64 * h + 64].t() for h in range(8)])
+    assert torch.isfinite(part).all()
+    err = rel_l2(part, ref)
+    print("attn_self_proj partials rel_l2", err)
+    assert err < 8e-3                                                             # P and O pass through bf16 once each
+
+
+@pytest.mark.parametrize("B", [1, 4])
+def test_xattn_q2_proj_partials_vs_torch(B):
+    import ctypes as C
+    from rald_amd._lib import check, lib
+    g = torch.Generator("cpu").manual_seed(4)
+    D, NL, T, L, li = 512, 512, 64, 3, 1                                          # cache of a 3-block model, block 1
+    M = B * NL
+    hin = torch.randn(M, D, generator=g).cuda().bfloat16()
+    Wq = (torch.randn(D, D, generator=g) / 22).cuda().bfloat16()
+    Wo = (torch.randn(D, D, generator=g) / 22).cuda().bfloat16()
+    Kc = torch.randn(B * T, L * D, generator=g).cuda().bfloat16()                 # [B*T][L*D]
+    Vt = torch.randn(B, L * D, T, generator=g).cuda().bfloat16()                  # [B][L*D][T]
+    part = torch.full((8, M, D), float("nan"), device="cuda")
+    qscale = 0.125 * 1.4426950408889634
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib().rald_op_xattn_q2_proj(_c(hin), _c(Wq), C.c_void_p(Kc.data_ptr() + li * D * 2), L * D, T * L * D,
+                                      C.c_void_p(Vt.data_ptr() + li * D * T * 2), T, L * D * T, _c(Wo), _c(part), M, NL, 8, T, qscale, C.c_void_p(st)))
+    q = (hin.float() @ Wq.float().t()).view(B, NL, 8, 64).permute(0, 2, 1, 3)     # [B,8,NL,64]
+    k = Kc.float().view(B, T, L, 8, 64)[:, :, li].permute(0, 2, 1, 3)             # [B,8,T,64]
+    v = Vt.float().view(B, L, 8, 64, T)[:, li].permute(0, 1, 3, 2)                # [B,8,T,64]
+    p = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1)
+    o = p @ v
+    ref = torch.stack([o[:, h].reshape(M, 64) @ Wo.float()[:, 64 * h:64 * h + 64].t() for h in range(8)])
+    assert torch.isfinite(part).all()
+    err = rel_l2(part, ref)
+    print("xattn_q2_proj partials rel_l2", err)
+    assert err < 1e-2                                                             # q, P and O pass through bf16 once each
+
+
+def test_reduce_resid_ln_matches_torch():
+    import ctypes as C
+    from rald_amd._lib import check, lib
+    g = torch.Generator("cpu").manual_seed(5)
+    M, D, S = 1024, 512, 8
+    part = torch.randn(S, M, D, generator=g).cuda()
+    bias = torch.randn(D, generator=g).cuda()
+    x = torch.randn(M, D, generator=g).cuda()
+    mod = torch.randn(2, 2 * D, generator=g).cuda()                               # two samples: per-sample (scale | shift)
+    ref_x = x + bias + part.sum(0)
+    ln = torch.nn.functional.layer_norm(ref_x, (D,))
+    ref_h = torch.cat([ln[:512] * (1 + mod[0, :D]) + mod[0, D:], ln[512:] * (1 + mod[1, :D]) + mod[1, D:]])
+    h = torch.empty(M, D, device="cuda", dtype=torch.bfloat16)
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib().rald_op_reduce_resid_ln(_c(part), S, M * D, _c(bias), _c(x), _c(h), M, _c(mod), C.c_void_p(mod.data_ptr() + D * 4), 2 * D, 512, 1.0, 1e-5,
+                                        C.c_void_p(st)))
+    assert rel_l2(x, ref_x) < 1e-6
+    assert rel_l2(h.float(), ref_h) < 4e-3
