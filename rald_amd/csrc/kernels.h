@@ -106,8 +106,9 @@ int xattn_q2_proj(const bf16* hin, const bf16* Wq, const bf16* Kc, int64_t ldk, 
 // x[M][512] += bias + sum_s part[s]; optionally h = LN(x) * (add_one + g) + b  (norm.hip; deterministic order)
 int reduce_resid_ln(const float* part, int S, int64_t part_stride, const float* bias, float* x, bf16* h, int M, const float* g, const float* b,
                     int64_t gstride, int rows_per_group, float add_one, float eps, hipStream_t st);
-// row count up to which the fused small-batch sub-blocks are used (measured on MI355X, tools/sweep_nfe.py)
-inline bool small_m_fused(int M, int NL, int heads, int D, int n_keys) { if (getenv("RALD_DBG_NOFUSE")) return false; return M <= 2048 && (NL == 256 || NL == 512) && heads == 8 && D == 512 && n_keys == 64; }
+// row count up to which the fused small-batch sub-blocks are used (measured on MI355X, tools/sweep_nfe.py: per NFE at B = 1 / 2 / 4
+// 1.41 / 1.70 / 2.59 ms fused against 1.64 / 1.89 / 2.27 ms unfused - from 2048 rows on the plain kernels fill the chip)
+inline bool small_m_fused(int M, int NL, int heads, int D, int n_keys) { return M <= 1024 && NL == 512 && heads == 8 && D == 512 && n_keys == 64; }
 
 // ---------------------------------------------------------------- small.hip
 enum { ACT_NONE = 0, ACT_SILU = 1 };

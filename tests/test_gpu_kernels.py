@@ -231,7 +231,7 @@ def _c(t):
     return C.c_void_p(t.data_ptr() if t is not None else 0)
 
 
-@pytest.mark.parametrize("NL,B", [(512, 1), (512, 3), (256, 2)])
+@pytest.mark.parametrize("NL,B", [(512, 1), (512, 3)])
 def test_attn_self_proj_partials_vs_torch(NL, B):
     """part[h] = softmax(q_h k_h^T) v_h . Wo[:, 64h:64h+64]^T per head; sum_h part[h] = to_out(attention) without bias."""
     import ctypes as C
