@@ -7,8 +7,11 @@ metric   : denoising steps/sec (whole node) = sample*NFE per second: one forward
 workload : BASELINE.json configs[2] - models_radar_generation DiT denoiser
            (kl_d512_m512_l32_d24_edm) on random 512x32 latents + synthetic radar-spectrum
            condition tokens [B,64,512]; seeded random weights (no checkpoints exist offline).
-extras   : AE encode / decode latency (configs[1]) and the 18-step sampler rate are reported
-           as extra keys of the same JSON line when --extras is on (default at N=1).
+extras   : the AE half of the metric (configs[1]: encode / decode ms + `roofline_ae`, one object per leg), the config-#4 chain
+           (radar cube -> 18-step sample -> decode of 1.2 M + 500 k queries, frames/s) and, at N > 1, one data-parallel
+           training step with the RCCL gradient exchange are appended to the same JSON line.
+guard    : every RALD_* environment variable is recorded in config.env; the run exits non-zero if the loaded library is a
+           PROBE build (the only build with work-skipping switches) or if a probe-only / library-override variable is set.
 
 Multi-GPU (driver launches torchrun, one rank per GPU): samples are independent, so the batch
 is sharded across ranks with NO data-path collective ("weak" scaling: B per GPU is fixed);
@@ -29,6 +32,27 @@ sys.path.insert(0, ROOT)
 
 GFLOP_PER_NFE = 132.18          # SURVEY.md §8d / BASELINE.md §3 (multiply-add = 2 FLOP)
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip table)
+
+
+# variables that only a PROBE build of the library reads (rald_amd/csrc/common.h), plus the library override itself
+PROBE_ONLY_ENV = ("RALD_GEMM_ABLATE", "RALD_NT_STORE", "RALD_FUSE_LN", "RALD_ATTN_VROW", "RALD_ATTN_PRESCALED", "RALD_GEMM_IMPL", "RALD_GEMM_MID",
+                  "RALD_SPLITK_MAXM", "RALD_CONV_LINE", "RALD_GN_FUSE", "RALD_CONV_SPLITK", "RALD_LIB_OVERRIDE")
+
+
+def env_guard():
+    """config.env for the JSON line; refuses to measure anything but the shipped library at its shipped settings."""
+    env = {k: v for k, v in sorted(os.environ.items()) if k.startswith("RALD_")}
+    bad = [k for k in env if k in PROBE_ONLY_ENV]
+    if bad:
+        print(f"[bench] refusing to run: {bad} are probe-build / override switches; a number measured with them is not the product's",
+              file=sys.stderr, flush=True)
+        sys.exit(3)
+    from rald_amd import _lib
+    flags = _lib.lib().rald_build_flags()
+    if flags != 0:
+        print(f"[bench] refusing to run: {_lib.LIB_PATH} is a PROBE build (rald_build_flags() = {flags})", file=sys.stderr, flush=True)
+        sys.exit(3)
+    return env
 
 
 def log(msg):
@@ -139,6 +163,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    env = env_guard()
     world, rank, local = dist_setup(args.gpus)
     from rald_amd import synth
     depth = 24
@@ -188,7 +213,7 @@ def main():
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "configs[2]: kl_d512_m512_l32_d24_edm denoiser NFE, 512x32 latents, 64x512 radar condition tokens (cached)",
                    "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"batch-sharded x{world}, no data-path collective",
-                   "weights": "seeded random (rald_amd.weights, seed 0)"},
+                   "weights": "seeded random (rald_amd.weights, seed 0)", "env": env},
         "whole_path_tflops": value * GFLOP_PER_NFE / 1e3,
         "heun_steps_per_s": value * 18.0 / 35.0, "samples_per_s_18step": value / 35.0,
         "roofline": {"bound": "mfma", "kernel": "rald::gemm_nt_glds_kernel<256,256,4,2,2,EPI_GEGLU> (FF1: [B*512,512]x[512,4096]^T, GEGLU epilogue)",
@@ -202,10 +227,23 @@ def main():
         out["cpu_baseline"] = cpu_baseline_nfe(sd, depth)
     elif rank == 0:
         out["cpu_baseline"] = None
+    if not args.no_extras:
+        # every rank runs these two legs on its own shard (frames / training samples are independent; the training step
+        # exchanges gradients over RCCL); rank 0 reports the whole-job rates
+        from rald_amd import bench_extras
+        for name, fn in (("config4", bench_extras.config4_leg), ("ddp_step", bench_extras.ddp_step_leg)):
+            try:
+                barrier(world)
+                res = fn(rank, world)
+                res["seconds"] = max_over_ranks(res["seconds"], world)
+                res["value"] = res.pop("units_all_ranks") / res["seconds"]
+                out[name] = res
+            except Exception as e:      # secondary legs never invalidate the headline line
+                out[name] = {"error": repr(e)}
+            barrier(world)
     if rank == 0 and world == 1 and not args.no_extras:
         log("extras: sampler / AE timings")
         try:
-            from rald_amd import bench_extras
             out.update(bench_extras.run(h))
         except Exception as e:  # extras never invalidate the headline line
             out["extras_error"] = repr(e)

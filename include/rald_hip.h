@@ -26,6 +26,10 @@ extern "C" {
 
 const char* rald_last_error(void);
 int rald_version(void);
+/* bit 0: PROBE build (`make PROBE=1`): the only build whose kernels honour the RALD_* A/B and ablation environment
+ * switches, some of which skip work (no DMA in a main loop, no epilogue stores).  0 for the shipped library, which reads no
+ * environment variable at all; bench.py refuses to measure a library that reports anything else. */
+int rald_build_flags(void);
 
 /* ------------------------------------------------------------------------------------------
  * Denoiser: EDMPrecond + LatentArrayTransformer  (model/models_radar_generation.py:171-233,

@@ -36,6 +36,7 @@ class AeConfig(C.Structure):
 SIGNATURES = {
     "rald_last_error": (c_char_p, []),
     "rald_version": (c_int, []),
+    "rald_build_flags": (c_int, []),
     "rald_dit_default_config": (None, [C.POINTER(DitConfig)]),
     "rald_dit_create": (c_int, [C.POINTER(DitConfig), C.POINTER(c_void_p)]),
     "rald_dit_destroy": (None, [c_void_p]),

@@ -62,4 +62,42 @@ def run(batches=(1, 8)) -> dict:
     gt = PP.polar2cartesian(PP.inverse_norm_points(synth.point_cloud(1, 10000, seed=9)[0].cuda(), pc_range, True, False))
     out["post_chamfer_n_pred"] = int(pts.shape[0])
     out["post_chamfer_ms"] = _time(lambda: PP.cal_metrics(pts, gt), reps=3)
+    out["roofline_ae"] = rooflines(out)
     return out
+
+
+PEAK_BF16_TFLOPS = 2500.0                   # dense bf16 MFMA (MI355X_MICROARCH.md, chip table)
+PEAK_HBM_GBPS = 8000.0
+# v_exp_f32 issues in 8 cycles per wave64 instruction (MI355X_MICROARCH.md, per-instruction cycle constants): 8 lanes/clk/SIMD
+PEAK_EXP_PER_S = 256 * 4 * 8 * 2.4e9
+
+
+def rooflines(t: dict) -> dict:
+    """One object per AE leg (the 'AE enc/dec ms' half of BASELINE.json's metric).  Algorithmic work per unit is SURVEY.md
+    section 8d's: encode 47.06 GFLOP per cloud of 10 000 points, latent stack 116.52 GFLOP per latent set - both dense
+    contractions, priced against the bf16 MFMA peak - and the query decoder, whose folded form (rald_amd/csrc/ae_decode.hip)
+    executes 512 exponentials + 0.07 MFLOP per query and moves 16 B: priced against the v_exp_f32 issue rate, with its HBM
+    fraction and the reference-equivalent rate (2.15 MFLOP per query as the reference computes it) beside it."""
+    r = {}
+    for B in (1, 8):
+        for leg, key, gflop in (("encode", f"ae_encode_ms_B{B}", 47.06), ("decode_latents", f"ae_decode_latents_ms_B{B}", 116.52)):
+            ach = gflop * B / t[key]                                    # GFLOP / ms = TFLOP/s
+            r[f"{leg}_B{B}"] = {"bound": "mfma", "ms": t[key], "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                "frac": ach / PEAK_BF16_TFLOPS, "algorithmic_gflop_per_launch": gflop * B}
+    ms = t["ae_decode_queries_1200k_ms_B1"]
+    exps = 512 * 1.2e6 / (ms * 1e-3)
+    r["decode_queries_1200k_B1"] = {"bound": "valu", "kernel": "rald::ae_decode_stream_kernel (one launch)", "ms": ms, "achieved": exps / 1e12,
+                                    "peak": PEAK_EXP_PER_S / 1e12, "unit": "T exp/s", "frac": exps / PEAK_EXP_PER_S,
+                                    "algorithmic_bytes_per_launch": 16 * 1.2e6, "hbm_gbps": 16 * 1.2e6 / (ms * 1e-3) / 1e9,
+                                    "hbm_frac": 16 * 1.2e6 / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                                    "reference_equivalent_tflops": 2.150e6 * 1.2e6 / (ms * 1e-3) / 1e12, "traffic": _traffic("ae_decode_queries_1200k")}
+    return r
+
+
+def _traffic(key):
+    import json, os
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+    try:
+        return json.load(open(p)).get(key)
+    except Exception:
+        return None

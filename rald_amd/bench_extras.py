@@ -37,7 +37,7 @@ def run(dit_handle) -> dict:
         out.update(_two_streams(dit_handle))
     except Exception as e:
         out["two_streams_error"] = repr(e)
-    for name, fn in (("streams", _sampler_streams), ("fp8", _fp8_mode), ("train", _train_step)):
+    for name, fn in (("streams", _sampler_streams), ("fp8", _fp8_mode)):
         try:
             out.update(fn())
         except Exception as e:          # secondary numbers never invalidate the headline line
@@ -126,3 +126,56 @@ def _train_step(B=8) -> dict:
     rnd, noise = synth.normal([B], 2), synth.normal([B, 512, 32], 3).cuda()
     dt = _time(lambda: tr.step(y, cube, rnd, noise), reps=3, warm=2)
     return {"train_step_ms_B8": dt * 1e3, "train_samples_per_s_B8": B / dt}
+
+
+def _edm24():
+    from . import config, models_radar_generation as G, weights
+    m = G.EDMPrecond(n_latents=512, channels=32, depth=24, configs=config.shipped_generation_config())
+    m.load_state_dict(weights.make_state_dict(weights.dit_spec(depth=24), 0), strict=True)
+    return m.cuda()
+
+
+def config4_leg(rank: int, world: int, frames: int = 4) -> dict:
+    """BASELINE config #4, the reference's evaluate chain at its own eval_batch_size = 1 (engine_generation.py:173-300): per
+    frame radar cube -> EDMPrecond.sample (18 Heun steps, condition encoded once) -> vae.decode on 1.2 M query points ->
+    refine pass on 500 k queries (the latent stack runs once per frame).  Each rank processes its own `frames` frames; no
+    collective.  Returns seconds for this rank's frames and the number of frames over all ranks."""
+    from . import bench_ae, engine_generation as E
+    m, vae = _edm24(), bench_ae.build_ae()
+    q1, q2 = synth.queries(1, 1200000, seed=11).cuda(), synth.queries(1, 500000, seed=12).cuda()
+    cubes = [synth.radar_cube(1, seed=4000 + rank * frames + i).cuda() for i in range(frames)]
+    E.sample_and_decode(m, vae, cubes[0], [q1, q2], batch_seeds=torch.tensor([0]))          # warm-up: graph capture, workspaces
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i, c in enumerate(cubes):
+        out = E.sample_and_decode(m, vae, c, [q1, q2], batch_seeds=torch.tensor([rank * frames + i]))
+    n_occ = int(out["occupied"][0].sum())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"seconds": dt, "units_all_ranks": frames * world, "unit": "frames/s", "frames_per_rank": frames, "eval_batch_size": 1,
+            "queries_per_frame": 1700000, "ms_per_frame_this_rank": dt / frames * 1e3, "occupied_last_frame": n_occ,
+            "workload": "configs[3]: radar cube -> 18-step sample -> decode 1.2 M + 500 k queries, batch-sharded, no collective"}
+
+
+def ddp_step_leg(rank: int, world: int, B: int = 8, steps: int = 3) -> dict:
+    """One data-parallel training iteration as main_generation.py / engine_generation.py:74-110 run it (DDP over the batch,
+    radar encoder trained jointly): forward + backward of EDMLoss through encoder and 24 blocks, bucketed gradient SUM over
+    RCCL (train_utils.GradReducer, 1/world folded into the clip), clip_grad_norm_(10), fused AdamW + EMA.  B samples per GPU."""
+    from . import train_dit as TD
+    from .train_utils import FlatAdamW, GradReducer
+    m = _edm24()
+    opt = FlatAdamW(list(m.parameters()), lr=1e-4, ema=True)
+    red = GradReducer(opt.flat_g) if world > 1 else None
+    tr = TD.EdmTrainer(m, opt, reducer=red)
+    y, cube = synth.normal([B, 512, 32], 100 + rank).cuda(), synth.radar_cube(B, seed=200 + rank).cuda()
+    rnd, noise = synth.normal([B], 300 + rank), synth.normal([B, 512, 32], 400 + rank).cuda()
+    tr.step(y, cube, rnd, noise)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, norm = tr.step(y, cube, rnd, noise)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"seconds": dt, "units_all_ranks": steps * B * world, "unit": "training samples/s", "batch_per_gpu": B, "steps": steps,
+            "ms_per_step_this_rank": dt / steps * 1e3, "loss": float(loss), "grad_norm": float(norm),
+            "gradient_exchange": "RCCL all-reduce, 64 MiB buckets of the flat fp32 gradient (735 MB)" if world > 1 else "none (1 GPU)"}

@@ -402,7 +402,7 @@ int Ae::decode_latents(const float* z, int B, void* ctx, hipStream_t st) {
     const int M = cfg.num_latents, L = cfg.latent_dim, BM = B * M;
     const float scale = 1.0f / sqrtf((float)cfg.dim_head);
     RALD_TRY(small_k_linear(z, w_proj, b_proj, x_x, BM, L, d, st));                     // x = proj(z)  (:410)
-    static const bool fuse_env = !(getenv("RALD_FUSE_LN") && atoi(getenv("RALD_FUSE_LN")) == 0);
+    static const bool fuse_env = RALD_PROBE_ENV("RALD_FUSE_LN", 1) != 0;
     const bool fuse_ok = fuse_env && d == 512;                              // the fused epilogue owns whole 512-wide rows
     auto resid_ln = [&](const bf16* A, int64_t lda, const bf16* W, int64_t ldw, const float* bias, int K, const float* ng, const float* nb) -> int {
         if (d == 512 && splitk_for(BM, K))

@@ -13,7 +13,14 @@ struct rald_ae { Ae impl; };
 extern "C" {
 
 const char* rald_last_error(void) { return rald::last_error(); }
-int rald_version(void) { return 1; }
+int rald_version(void) { return 2; }
+int rald_build_flags(void) {
+#ifdef RALD_PROBE
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 void rald_dit_default_config(rald_dit_config* c) {
     c->n_latents = 512; c->channels = 32; c->depth = 24; c->n_heads = 8; c->d_head = 64; c->t_channels = 256;
@@ -248,7 +255,7 @@ int rald_op_gemm_nt(const void* A, int64_t lda, int64_t strideA, const void* B, 
     GemmArgs g;
     g.A = (const bf16*)A; g.lda = lda; g.strideA = strideA; g.B = (const bf16*)B; g.ldb = ldb; g.strideB = strideB;
     g.C = C; g.ldc = ldc; g.strideC = strideC; g.bias = bias; g.M = M; g.N = N; g.K = K; g.batch = batch; g.alpha = alpha; g.alpha_ncols = 1 << 30; g.ablate = 0;
-    if (const char* e = getenv("RALD_GEMM_ABLATE")) g.ablate = atoi(e);
+    g.ablate = RALD_PROBE_ENV("RALD_GEMM_ABLATE", 0);
     return gemm_nt(g, epilogue, (hipStream_t)stream);
 }
 int rald_op_gemm_nt2(const void* A, int64_t lda, int64_t strideA, int64_t strideA2, const void* B, int64_t ldb, int64_t strideB, int64_t strideB2,
@@ -388,7 +395,7 @@ int rald_op_attention(const void* Q, int64_t ldq, int64_t strideQ, const void* K
     a.Q = (const bf16*)Q; a.ldq = ldq; a.strideQ = strideQ; a.K = (const bf16*)K; a.ldk = ldk; a.strideK = strideK;
     a.Vt = (const bf16*)Vt; a.ldvt = ldvt; a.strideVt = strideVt; a.O = (bf16*)O; a.ldo = ldo; a.strideO = strideO;
     a.nq = nq; a.nk = nk; a.k_rows = k_rows; a.heads = heads; a.batch = batch; a.scale = scale; a.q_prescaled = 0;
-    if (const char* e = getenv("RALD_ATTN_PRESCALED")) a.q_prescaled = atoi(e);   // timing experiments only
+    a.q_prescaled = RALD_PROBE_ENV("RALD_ATTN_PRESCALED", a.q_prescaled);   // timing experiments (probe builds)
     return attention_d64(a, (hipStream_t)stream);
 }
 int64_t rald_op_attention_split_scratch_bytes(int32_t ksplit, int32_t nq, int32_t heads, int32_t batch) {

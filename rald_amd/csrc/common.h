@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 #include <string>
 
 namespace rald {
@@ -37,6 +38,19 @@ void set_error(const std::string& msg);
         int _rc = (expr);                                                           \
         if (_rc) return _rc;                                                        \
     } while (0)
+
+// ---- run-time switches: PROBE builds only ------------------------------------------------------
+// The shipped library (make -> librald_hip.so) reads NO environment variable: every A/B switch and every diagnostic that
+// skips work (no DMA in a main loop, no epilogue stores ...) exists only in `make PROBE=1` -> librald_hip_probe.so, which
+// tools/ load explicitly through RALD_LIB_OVERRIDE and which bench.py refuses to measure.
+#ifdef RALD_PROBE
+inline int probe_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#define RALD_PROBE_ENV(name, dflt) (::rald::probe_env(name, dflt))
+#define RALD_ABLATED(flags, bit) (((flags) & (bit)) != 0)
+#else
+#define RALD_PROBE_ENV(name, dflt) (dflt)
+#define RALD_ABLATED(flags, bit) false
+#endif
 
 // ---- device helpers --------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

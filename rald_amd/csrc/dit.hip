@@ -407,8 +407,8 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
     const float scale = 1.0f / sqrtf((float)cfg.d_head);
     const float qscale = scale * 1.4426950408889634f;     // softmax scale and log2(e) folded into q by the projection epilogue
 
-    // RALD_FUSE_LN=0 falls back to separate LayerNorm launches (A/B and debugging)
-    static const bool fuse_ln = !(getenv("RALD_FUSE_LN") && atoi(getenv("RALD_FUSE_LN")) == 0);
+    // probe builds: RALD_FUSE_LN=0 falls back to separate LayerNorm launches (A/B and debugging)
+    static const bool fuse_ln = RALD_PROBE_ENV("RALD_FUSE_LN", 1) != 0;
     auto resid_ln = [&](const bf16* A, int64_t lda, const bf16* W, int64_t ldw, const float* bias, int K, const float* mnext) -> int {
         // x += A.W^T + bias, then (if mnext) h = AdaLN(x; mnext) for the next sub-block
         if (splitk_for(M, K))
@@ -531,7 +531,7 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
         (void)m1;
         // one projection for q | k | v (N = 1536); the attention kernel reads V row-major through ds_read_b64_tr_b16, so no
         // transposed copy of V and no separate V^T GEMM (RALD_ATTN_VROW=0: the two-GEMM form, for A/B runs)
-        static const bool vrow_env = !(getenv("RALD_ATTN_VROW") && atoi(getenv("RALD_ATTN_VROW")) == 0);
+        static const bool vrow_env = RALD_PROBE_ENV("RALD_ATTN_VROW", 1) != 0;
         const bool vrow = vrow_env && NL % 64 == 0;
         AttnArgs a1;
         if (vrow) {

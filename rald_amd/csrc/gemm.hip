@@ -312,7 +312,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_glds_kernel(GemmArgs a) 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (nk > 1 && !(a.ablate & 1)) stage(1, 1);
+        if (nk > 1 && !RALD_ABLATED(a.ablate, 1)) stage(1, 1);
         read_frags(0, 0, fa0, fb0);
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_glds_kernel(GemmArgs a) 
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tile kt+1 landed; my reads of tile kt are done
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if (kt + 2 < nk && !(a.ablate & 1)) stage(kt + 2, cur);      // buffer `cur` is free now
+                if (kt + 2 < nk && !RALD_ABLATED(a.ablate, 1)) stage(kt + 2, cur);      // buffer `cur` is free now
                 read_frags(cur ^ 1, 0, fa0, fb0);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_glds_kernel(GemmArgs a) 
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_barrier();          // everyone's pieces of tile kt are in LDS; buffer (kt-1)%NSTAGE is free
             asm volatile("" ::: "memory");
-            if (kt + NSTAGE - 1 < nk && !(a.ablate & 1)) stage(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);
+            if (kt + NSTAGE - 1 < nk && !RALD_ABLATED(a.ablate, 1)) stage(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 bf16x8 fa[MT], fb[NT];
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_glds_kernel(GemmArgs a) 
             }
         }
     }
-    if (a.ablate & 2) {                       // diagnostics: keep the accumulators live, store (almost) nothing
+    if (RALD_ABLATED(a.ablate, 2)) {          // probe builds: keep the accumulators live, store (almost) nothing
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -417,10 +417,10 @@ static int gemm_nt_impl(const GemmArgs& a, int epi, hipStream_t st);
 int gemm_nt(const GemmArgs& a0, int epi, hipStream_t st) {
     // bf16 outputs are streamed (written once, read by the next kernel after the whole tensor has
     // passed through): non-temporal stores keep them from evicting the weight panels out of L2.
-    static const int nt_store = getenv("RALD_NT_STORE") ? atoi(getenv("RALD_NT_STORE")) : 1;
+    static const int nt_store = RALD_PROBE_ENV("RALD_NT_STORE", 1);
     GemmArgs a = a0;
     if (nt_store) a.ablate |= 64;
-    static const int diag = getenv("RALD_GEMM_ABLATE") ? atoi(getenv("RALD_GEMM_ABLATE")) : 0;   // diagnostics (PMC runs): OR-ed into GemmArgs::ablate
+    static const int diag = RALD_PROBE_ENV("RALD_GEMM_ABLATE", 0);   // probe builds (PMC runs): OR-ed into GemmArgs::ablate
     a.ablate |= diag;
     return gemm_nt_impl(a, epi, st);
 }
@@ -451,13 +451,13 @@ static int gemm_nt_impl(const GemmArgs& a, int epi, hipStream_t st) {
     // 0 register-staged 128x128, 1 LDS-DMA 128x128 2 stages, 2 ... 3 stages, 3 LDS-DMA 256x128 2 stages,
     // 4 256x128 3 stages, 5 256x256 2 stages.
     int impl = -1;
-    if (const char* e = getenv("RALD_GEMM_IMPL")) impl = atoi(e);
+    impl = RALD_PROBE_ENV("RALD_GEMM_IMPL", -1);
     const int64_t wg128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) * nbatch;
     if (wg128 < 192) {
         // small-M (batch-1) regime: too few tiles to hide memory latency behind other workgroups, so put
         // (up to) the whole K extent in flight at once: 64x64 tiles, 8-stage LDS-DMA ring (128 KB).
         const int64_t wg64 = (int64_t)cdiv(a.M, 64) * cdiv(a.N, 64) * nbatch;
-        static const int mid = getenv("RALD_GEMM_MID") ? atoi(getenv("RALD_GEMM_MID")) : 0;   // A/B: 1 = LDS-DMA 128x128 from 96 tiles up, 2 = LDS-DMA 64x64 ring always
+        static const int mid = RALD_PROBE_ENV("RALD_GEMM_MID", 0);   // A/B: 1 = LDS-DMA 128x128 from 96 tiles up, 2 = LDS-DMA 64x64 ring always
         if (mid == 1 && wg128 >= 96) return launch_glds<128, 128, 2, 2, 2>(a, epi, st);
         if (mid == 2) return launch_glds<64, 64, 2, 2, 8>(a, epi, st);
         if (impl == 0 || wg64 > 256) return launch_tile<64, 64>(a, epi, st);   // more than one tile per CU: 5 small workgroups/CU hide latency

@@ -80,7 +80,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[MT][NT], const Ge
                     continue;
                 }
             }
-            if (m < a.M && c < ncols && !(a.ablate & 16)) {      // 16: diagnostics, no global stores
+            if (m < a.M && c < ncols && !RALD_ABLATED(a.ablate, 16)) {      // 16: probe builds, no global stores
                 if constexpr (EPI == EPI_RESID) {
                     float* C = reinterpret_cast<float*>(a.C) + coff + (int64_t)m * a.ldc + c;
                     float4 x = *reinterpret_cast<float4*>(C);

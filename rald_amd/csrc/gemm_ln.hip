@@ -225,7 +225,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs 
     }
 
     const bool nt_io = (a.nt_io & 1) != 0;
-    const bool skip_x = (a.nt_io & 2) != 0, skip_h = (a.nt_io & 4) != 0;   // RALD_NT_STORE bits 1 / 2: timing ablations only
+    const bool skip_x = RALD_ABLATED(a.nt_io, 2), skip_h = RALD_ABLATED(a.nt_io, 4);   // probe builds, RALD_NT_STORE bits 1 / 2: timing ablations
     // ---- 1. v = acc + bias + x_old (accumulator layout), row partial sums -------------------------
     const int mb = m0 + wm * (BM / WM);
     const int nb = wn * (BN / WN);
@@ -363,7 +363,7 @@ static int launch_ln(const GemmLnArgs& a, hipStream_t st) {
 }
 
 int gemm_resid_ln(const GemmLnArgs& a0, hipStream_t st) {
-    static const int nt_env = getenv("RALD_NT_STORE") ? atoi(getenv("RALD_NT_STORE")) : 1;
+    static const int nt_env = RALD_PROBE_ENV("RALD_NT_STORE", 1);
     GemmLnArgs a = a0;
     a.nt_io = nt_env;
     const bool mx = a.A8 != nullptr;                         // MXFP8 operands: A8/SA and W8/SW instead of A and W

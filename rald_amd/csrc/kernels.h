@@ -17,7 +17,7 @@ struct GemmArgs {
     int M, N, K, batch;
     float alpha;
     int alpha_ncols;                               // alpha applies to output columns n < alpha_ncols only (others use 1)
-    int ablate;                                    // diagnostics only (RALD_GEMM_ABLATE): 1 = no DMA in the loop, 2 = no epilogue
+    int ablate;                                    // bit 64: non-temporal output stores.  Probe builds only (RALD_ABLATED): 1 = no DMA in the loop, 2 = no epilogue, 16 = no stores
     // optional inner batch (attention heads): grid z = batch * batch2, blockIdx.z = b1 * batch2 + b2,
     // operand offset = b1 * stride + b2 * stride2
     int batch2 = 1;
@@ -180,7 +180,7 @@ int quantize_mx8(const void* in, int in_is_bf16, int64_t ld_in, unsigned char* q
 int resid_splitk_ln(const bf16* A, int64_t lda, const bf16* W, int64_t ldw, const float* bias, float* x, bf16* h, const float* g, const float* b,
                     int64_t gstride, int rows_per_group, float add_one, float eps, int M, int K, int splits, float* scratch, hipStream_t st);
 inline int splitk_max_rows() {                      // RALD_SPLITK_MAXM: A/B switch for the row count up to which split-K pays
-    static const int v = getenv("RALD_SPLITK_MAXM") ? atoi(getenv("RALD_SPLITK_MAXM")) : 4096;
+    static const int v = RALD_PROBE_ENV("RALD_SPLITK_MAXM", 4096);
     return v;
 }
 inline int splitk_for(int M, int K) { return (K >= 2048 && M <= splitk_max_rows()) ? 4 : 0; }   // [M,512] outputs: few 128x128 tiles

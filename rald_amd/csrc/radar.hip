@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void conv3d_line_kernel(ConvArgs a, int lw) {
 
 // engine choice for one convolution (RALD_CONV_LINE=0 keeps the per-tap gather kernel everywhere: A/B switch)
 static void launch_conv(const ConvArgs& a, hipStream_t st) {
-    static const bool line = !(getenv("RALD_CONV_LINE") && atoi(getenv("RALD_CONV_LINE")) == 0);
+    static const bool line = RALD_PROBE_ENV("RALD_CONV_LINE", 1) != 0;
     const int64_t M = (int64_t)a.B * a.OD * a.OH * a.OW;
     const dim3 grid(cdiv(a.Cout, 64), (unsigned)((M + 127) / 128));
     const bool pow2 = a.OW == 8 || a.OW == 16 || a.OW == 32;
@@ -744,7 +744,7 @@ int RadarEncoder::Impl::ensure_ws(int nsub) {
 
 int RadarEncoder::Impl::gn(const float* x, const std::string& name, bf16* y, int B, int S, int C, bool swish, hipStream_t st) {
     RALD_CHECK(gn_blocks(S) <= gn_part_blocks, "radar encoder: GroupNorm partial buffer too small");
-    static const bool fuse = !(getenv("RALD_GN_FUSE") && atoi(getenv("RALD_GN_FUSE")) == 0);   // A/B switch
+    static const bool fuse = RALD_PROBE_ENV("RALD_GN_FUSE", 1) != 0;   // A/B switch
     if (fuse && x == fused_src && B == fused_B && S == fused_S && C == fused_C) {
         // the convolution that produced x left per-tile partials: no statistics pass over x
         hipLaunchKernelGGL(gn_finish_kernel, dim3(B), dim3(1024), 0, st, cpart, stats, S / 128);
@@ -771,7 +771,7 @@ int RadarEncoder::Impl::run_conv(const bf16* in, const std::string& name, const 
     const int64_t M = (int64_t)B * a.OD * a.OH * a.OW;
     const int So = a.OD * a.OH * a.OW;
     // few tiles x long K (the 512- and 64-voxel levels: 8-64 workgroups looping over 54-108 k-steps): split K over gridDim.z
-    static const bool split_ok = !(getenv("RALD_CONV_SPLITK") && atoi(getenv("RALD_CONV_SPLITK")) == 0);   // A/B switch
+    static const bool split_ok = RALD_PROBE_ENV("RALD_CONV_SPLITK", 1) != 0;   // A/B switch
     const int64_t tiles = (int64_t)cdiv(cout, 64) * ((M + 127) / 128);
     const int nk = 27 * (cin / 64);
     const bool line_engine = stride == 1 && pad == 1 && (a.OW == 8 || a.OW == 16 || a.OW == 32) && M % 128 == 0;

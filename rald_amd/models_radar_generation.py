@@ -179,10 +179,38 @@ def edm_sampler(net, latents, class_labels=None, cond_type=None, randn_like=torc
     return net._sample_from(latents, class_labels, cond_type, num_steps, sigma_min, sigma_max, rho)
 
 
+class _EdmDenoiseFn(torch.autograd.Function):
+    """EDMPrecond.forward as an autograd node: forward = radar encoder + tokeniser + 24-block denoiser + EDM pre/post-conditioning
+    through the HIP training kernels (rald_amd.train_encoder / train_dit, activations kept), backward = their hand-written
+    backward passes.  The module's parameters are inputs of the node, so ``loss.backward()`` fills ``p.grad`` the ordinary way
+    and ``DistributedDataParallel``'s reducer hooks fire on them (main_generation.py:157-159, utils/misc.py:255)."""
+
+    @staticmethod
+    def forward(ctx, module, x, sigma, cube, *params):
+        tr = module._autograd_trainers()
+        tokens = tr["enc"].forward(cube[..., 0:1].contiguous() if cube.shape[-1] != 1 else cube.contiguous())
+        D, st = tr["dit"].forward_denoised(x, tokens, sigma)
+        ctx.module, ctx.st = module, st
+        return D
+
+    @staticmethod
+    def backward(ctx, dD):
+        tr = ctx.module._autograd_trainers()
+        for sh in tr["shadow"].values():
+            sh.grad = None
+        dtok = tr["dit"].backward_denoised(ctx.st, dD.contiguous())
+        tr["enc"].backward(dtok)
+        ctx.st = None
+        grads = tuple(tr["shadow"][n].grad if tr["shadow"][n].grad is not None else torch.zeros_like(tr["shadow"][n])
+                      for n in tr["names"])
+        return (None, None, None, None) + grads
+
+
 class EDMLoss:
-    """:277-295, the reference's call signature and value (forward through the HIP denoiser).  Training - the same loss with
-    its backward pass, clip / AdamW / EMA - goes through ``rald_amd.train_dit.EdmTrainer``, which takes the two random
-    draws explicitly."""
+    """:277-295, the reference's call signature and value.  Under grad mode ``net(...)`` is differentiable (``_EdmDenoiseFn``):
+    ``EDMLoss()(model, latents, cube, 'radar').backward()`` - the reference's own training loop, also under torch DDP - works
+    unchanged.  ``rald_amd.train_dit.EdmTrainer`` is the fused alternative (loss + backward + clip / AdamW / EMA on flat
+    storage, the two random draws passed explicitly)."""
 
     def __init__(self, P_mean=-1.2, P_std=1.2, sigma_data=1):
         self.P_mean, self.P_std, self.sigma_data = P_mean, P_std, sigma_data
@@ -284,9 +312,43 @@ class EDMPrecond(_HipBacked):
         """(B,R,A,E,ch) -> (B, R'A'E', C) condition tokens (:363-407)."""
         return self._cond(radar_cube)[0]
 
+    def _autograd_trainers(self):
+        """The training kernels' view of this module for the autograd route: shadow Parameters that SHARE the real parameters'
+        storage (the trainers accumulate into `.grad` of what they are given; the real `.grad`s belong to autograd), rebuilt
+        when a parameter's storage moved, bf16 compute copies refreshed when a parameter's version did."""
+        from .train_dit import DitTrainer
+        from .train_encoder import EncoderTrainer
+        named = list(self.named_parameters())
+        ptrs = tuple(p.data_ptr() for _, p in named)
+        vers = tuple(p._version for _, p in named)
+        tr = self.__dict__.get("_ag_trainers")
+        if tr is None or tr["ptrs"] != ptrs:
+            shadow = {n: nn.Parameter(p.detach(), requires_grad=True) for n, p in named}
+            tr = dict(shadow=shadow, names=[n for n, _ in named], ptrs=ptrs, vers=vers,
+                      dit=DitTrainer({k[len("model."):]: v for k, v in shadow.items() if k.startswith("model.")}, self.depth,
+                                     n_heads=self.n_heads, sigma_data=float(self.sigma_data)),
+                      enc=EncoderTrainer({k: v for k, v in shadow.items() if k.startswith("radar_")}))
+            self.__dict__["_ag_trainers"] = tr
+        elif tr["vers"] != vers:
+            tr["dit"].refresh_weights()
+            tr["vers"] = vers
+        return tr
+
     def forward(self, x, sigma, label_tokens=None, cond_type=None, force_fp32=False, **model_kwargs):
         if cond_type != 'radar':
             raise NotImplementedError("cond_type must be 'radar'")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training: differentiable route (engine_generation.py:93-104: loss_scaler(loss, ...) -> loss.backward())
+            if x.requires_grad or label_tokens.requires_grad:
+                raise NotImplementedError("gradients with respect to the noised latents / the radar cube are not built "
+                                          "(the reference trains the parameters only: latents come from the frozen VAE)")
+            sig = torch.as_tensor(sigma, dtype=torch.float32).reshape(-1)
+            if sig.numel() == 1:
+                sig = sig.expand(x.shape[0])
+            if sig.numel() != x.shape[0]:
+                raise RuntimeError("sigma must be a scalar or have one entry per sample")
+            params = [p for _, p in self.named_parameters()]
+            return _EdmDenoiseFn.apply(self, x.to(torch.float32), sig, label_tokens, *params)
         h = self._handle()
         _, cache = self._cond(label_tokens, h)
         sig = torch.as_tensor(sigma, dtype=torch.float32).reshape(-1).cpu()

@@ -149,8 +149,11 @@ class DitTrainer:
     def edm_scalars(self, rnd_normal: torch.Tensor) -> torch.Tensor:
         """[B, 6] device table {sigma, c_in, c_noise, c_skip, c_out, weight} from the log-normal draw (:285-286, :422-425);
         tiny host math, like the reference's python arithmetic on [B,1,1] tensors."""
+        return self.edm_scalars_from_sigma(torch.exp(rnd_normal.double().cpu().flatten() * self.p_std + self.p_mean))
+
+    def edm_scalars_from_sigma(self, sigma: torch.Tensor) -> torch.Tensor:
         sd2 = self.sigma_data ** 2
-        sigma = torch.exp(rnd_normal.double().cpu().flatten() * self.p_std + self.p_mean)
+        sigma = sigma.double().cpu().flatten()
         c_skip, c_out = sd2 / (sigma ** 2 + sd2), sigma * self.sigma_data / torch.sqrt(sigma ** 2 + sd2)
         c_in, c_noise = 1.0 / torch.sqrt(sd2 + sigma ** 2), torch.log(sigma) / 4
         weight = (sigma ** 2 + sd2) / (sigma * self.sigma_data) ** 2
@@ -164,15 +167,46 @@ class DitTrainer:
     def forward_backward_device(self, y: torch.Tensor, cond_tokens: torch.Tensor, scal: torch.Tensor, noise: torch.Tensor):
         """Same with the per-sample scalars already on the device (``edm_scalars``): nothing here touches the host, so
         the whole call can be captured in a hipGraph (``GraphedTrainStep``)."""
-        P, D, H, L, dev = self.P, self.D, self.H, self.depth, self.dev
         Bn, NL, Cc = y.shape
+        M = Bn * NL
+        f32 = dict(device=self.dev, dtype=torch.float32)
+        y2 = y.reshape(M, Cc).to(**f32).contiguous()
+        xn = (y2.view(Bn, NL * Cc) + noise.reshape(Bn, NL * Cc).to(**f32) * scal[:, 0][:, None]).view(M, Cc).contiguous()
+        st = self.forward_core(xn, cond_tokens, scal, Bn, NL)
+        # ---- loss and its gradient --------------------------------------------------------------------------
+        coef3 = scal[:, 3:6].contiguous()
+        loss = torch.zeros(1, device=self.dev, dtype=torch.float64)
+        dF = torch.empty_like(st["F"])
+        check(lib().rald_op_edm_loss_grad(_p(st["F"]), _p(xn), _p(y2), _p(coef3), NL * Cc, M * Cc, _p(dF), _p(None), _p(loss), C.c_void_p(_stream())))
+        dcond = self.backward_core(st, dF)
+        return loss[0], dcond
+
+    def forward_denoised(self, x: torch.Tensor, cond_tokens: torch.Tensor, sigma: torch.Tensor):
+        """EDMPrecond.forward (:412-430) with everything the backward pass needs kept: x [B, N, C] (noised input), sigma one
+        value per sample -> (D_x [B, N, C] fp32, state).  ``backward_denoised(state, dD)`` then accumulates the parameter
+        gradients of a scalar whose gradient with respect to D_x is ``dD`` (the autograd route: models_radar_generation)."""
+        Bn, NL, Cc = x.shape
+        scal = self.edm_scalars_from_sigma(sigma)
+        xn = x.reshape(Bn * NL, Cc).to(device=self.dev, dtype=torch.float32).contiguous()
+        st = self.forward_core(xn, cond_tokens, scal, Bn, NL)
+        st["c_out"] = scal[:, 4].contiguous()
+        D = scal[:, 3].view(Bn, 1, 1) * xn.view(Bn, NL, Cc) + scal[:, 4].view(Bn, 1, 1) * st["F"].view(Bn, NL, Cc)
+        return D, st
+
+    def backward_denoised(self, st, dD: torch.Tensor) -> torch.Tensor:
+        Bn, NL = st["Bn"], st["NL"]
+        dF = (dD.to(torch.float32).reshape(Bn, -1) * st["c_out"][:, None]).reshape(Bn * NL, -1).contiguous()     # D = c_skip x + c_out F
+        return self.backward_core(st, dF)
+
+    def forward_core(self, xn: torch.Tensor, cond_tokens: torch.Tensor, scal: torch.Tensor, Bn: int, NL: int):
+        """timestep MLP -> 72 AdaLN linears -> proj_in -> blocks -> norm -> proj_out on xn [B*N, C]; returns the state dict
+        (F [B*N, C] and every saved activation)."""
+        P, D, H, L, dev = self.P, self.D, self.H, self.depth, self.dev
+        Cc = xn.shape[1]
         T = cond_tokens.shape[1]
         M = Bn * NL
         f32 = dict(device=dev, dtype=torch.float32)
-        sigma, c_in, c_noise = scal[:, 0], scal[:, 1], scal[:, 2].contiguous()
-        coef3 = scal[:, 3:6].contiguous()
-        y2 = y.reshape(M, Cc).to(**f32).contiguous()
-        xn = (y2.view(Bn, NL * Cc) + noise.reshape(Bn, NL * Cc).to(**f32) * sigma[:, None]).view(M, Cc).contiguous()
+        c_in, c_noise = scal[:, 1], scal[:, 2].contiguous()
         xin = (xn.view(Bn, NL * Cc) * c_in[:, None]).view(M, Cc).contiguous()
         # ---- timestep embedding (:217-219) and the 72 AdaLN modulations (:127-131) ---------------------------
         pe = torch.empty(Bn, P["map_layer0.weight"].shape[1], **f32)
@@ -189,16 +223,22 @@ class DitTrainer:
         saved = []
         for i in range(L):
             saved.append(TO.block_forward(self.W[i], x, mod[:, 3 * i:3 * i + 3], cond16, Bn, NL, H))
-        x_final = x
         ng, nb = P["norm.weight"].data, P["norm.bias"].data
-        yn = op_layernorm(x_final, ng, nb, gstride=0, rows_per_group=1 << 30, add_one=0.0).float()      # [M, 512]
+        yn = op_layernorm(x, ng, nb, gstride=0, rows_per_group=1 << 30, add_one=0.0).float()      # [M, 512]
         F = torch.zeros(M, Cc, **f32)
         sgemm_acc(yn, P["proj_out.weight"].data, F)
-        # ---- loss and its gradient --------------------------------------------------------------------------
-        loss = torch.zeros(1, device=dev, dtype=torch.float64)
-        dF = torch.empty_like(F)
-        check(lib().rald_op_edm_loss_grad(_p(F), _p(xn), _p(y2), _p(coef3), NL * Cc, M * Cc, _p(dF), _p(None), _p(loss), C.c_void_p(_stream())))
-        # ---- backward ---------------------------------------------------------------------------------------
+        return dict(F=F, x_final=x, yn=yn, xin=xin, pe=pe, a0=a0, e0=e0, a1=a1, temb=temb, mod=mod, cond16=cond16, saved=saved,
+                    Bn=Bn, NL=NL, T=T)
+
+    def backward_core(self, st, dF: torch.Tensor) -> torch.Tensor:
+        """Backward of forward_core from dF = d(scalar)/dF [B*N, C]: accumulates into every ``param.grad``, returns dcond [B, T, Cd]."""
+        P, D, L, dev = self.P, self.D, self.depth, self.dev
+        Bn, T = st["Bn"], st["T"]
+        x_final, yn, xin, saved, cond16 = st["x_final"], st["yn"], st["xin"], st["saved"], st["cond16"]
+        pe, a0, e0, a1, temb = st["pe"], st["a0"], st["e0"], st["a1"], st["temb"]
+        M = x_final.shape[0]
+        f32 = dict(device=dev, dtype=torch.float32)
+        ng = P["norm.weight"].data
         sgemm_acc(dF, yn, self._grad("proj_out.weight"), trans_a=True, trans_b=True)             # dW_out = dF^T . yn
         dyn = torch.zeros(M, D, **f32)
         sgemm_acc(dF, P["proj_out.weight"].data, dyn, trans_b=True)                              # dyn = dF . W_out
@@ -233,7 +273,7 @@ class DitTrainer:
         da0 = silu_bwd(a0, de0)
         sgemm_acc(da0, pe, self._grad("map_layer0.weight"), trans_a=True, trans_b=True)
         TO.colsum(da0, self._grad("map_layer0.bias"))
-        return loss[0], dcond.view(Bn, T, -1)
+        return dcond.view(Bn, T, -1)
 
 
 class GraphedTrainStep:

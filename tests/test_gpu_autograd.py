@@ -1,0 +1,147 @@
+"""The training boundary as the reference uses it (engine_generation.py:90-104, main_generation.py:157-161): EDMLoss()(model,
+latents, cube, 'radar') is an ordinary autograd scalar - loss.backward() (through NativeScaler's GradScaler) fills p.grad of
+every parameter, torch.optim.AdamW steps them, DistributedDataParallel averages them - with the HIP forward / backward kernels
+underneath (rald_amd.models_radar_generation._EdmDenoiseFn)."""
+import os
+
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _edm(depth=2):
+    from rald_amd import config, models_radar_generation as G, weights
+    m = G.EDMPrecond(n_latents=512, channels=32, depth=depth, configs=config.shipped_generation_config())
+    m.load_state_dict(weights.make_state_dict(weights.dit_spec(depth=depth), 0), strict=True)
+    return m.cuda()
+
+
+def _reference_style_loss(m, y, cube, g6, monkeypatch):
+    from rald_amd import models_radar_generation as G
+    monkeypatch.setattr(torch, "randn", lambda *a, **k: g6["rnd_normal"].cuda())
+    monkeypatch.setattr(torch, "randn_like", lambda t, **k: g6["noise"].cuda())
+    return G.EDMLoss()(m, y, cube, "radar")
+
+
+def test_loss_backward_fills_param_grads_like_the_reference(monkeypatch):
+    """Same model / inputs / draws as G6 and G16: loss value, total gradient norm and the three group norms against the
+    reference's autograd, every gradient against the fused trainer (same kernels)."""
+    from rald_amd import synth
+    from rald_amd.train_dit import EdmTrainer
+    from rald_amd.train_utils import FlatAdamW
+    g6, g16 = load_golden("g6_edmloss.npz"), load_golden("g16_edmloss_grad.npz")
+    m, m2 = _edm(2), _edm(2)                                           # (both before torch.randn is patched: the weights are drawn with it)
+    y, cube = synth.normal([2, 512, 32], 21).cuda(), synth.radar_cube(2).cuda()
+    loss = _reference_style_loss(m, y, cube, g6, monkeypatch)
+    assert loss.requires_grad and loss.grad_fn is not None
+    scale = 1024.0                                                      # GradScaler multiplies the loss before backward (utils/misc.py:255)
+    (loss * scale).backward()
+    print("loss", float(loss), "reference", float(g16["loss"]))
+    assert abs(float(loss) - float(g16["loss"])) < 2e-2 * float(g16["loss"])
+    sq = {"model": 0.0, "radar_enc": 0.0, "tokeniser": 0.0}
+    for n, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+        key = "model" if n.startswith("model.") else ("radar_enc" if n.startswith("radar_enc.") else "tokeniser")
+        sq[key] += float((p.grad.double() / scale).pow(2).sum())
+    total = sum(sq.values()) ** 0.5
+    print("grad norm", total, "reference", float(g16["grad_norm"]), {k: v ** 0.5 for k, v in sq.items()}, dict(zip(g16["group_names"], g16["group_norms"])))
+    assert abs(total - float(g16["grad_norm"])) < 3e-2 * float(g16["grad_norm"])
+    for name, ref in zip(g16["group_names"], g16["group_norms"]):
+        assert abs(sq[str(name)] ** 0.5 - float(ref)) < 4e-2 * float(ref)
+    # against the fused trainer on a second copy of the model
+    opt = FlatAdamW(m2.parameters(), lr=1e-4)
+    tr = EdmTrainer(m2, opt)
+    opt.zero_grad()
+    tr.forward_backward(y, cube, g6["rnd_normal"].flatten(), g6["noise"].cuda())
+    ga = torch.cat([(p.grad / scale).flatten() for p in m.parameters()])
+    gb = torch.cat([q.grad.flatten() for q in m2.parameters()])
+    # (per parameter only where the gradient is not numerically zero: a few attention key weights have gradients of ~1e-7 by
+    # softmax shift invariance, pure rounding noise in either route)
+    big = [(n, rel_l2(p.grad / scale, q.grad)) for (n, p), (_, q) in zip(m.named_parameters(), m2.named_parameters())
+           if float(q.grad.norm()) > 1e-3 * float(gb.norm())]
+    worst = max(big, key=lambda t: t[1])
+    print("whole gradient vs the fused trainer: rel_l2", rel_l2(ga, gb), "; worst parameter", worst, "of", len(big))
+    assert rel_l2(ga, gb) < 2e-3 and worst[1] < 1e-2
+
+
+def test_reference_training_iteration_with_torch_adamw(monkeypatch):
+    """engine_generation.py:93-110 verbatim in spirit: GradScaler-scaled backward, unscale_, clip_grad_norm_(10),
+    torch.optim.AdamW.step, then forward() must see the new weights (handle fingerprint on p._version)."""
+    from rald_amd import synth
+    g6 = load_golden("g6_edmloss.npz")
+    m = _edm(2)
+    y, cube, x01 = synth.normal([2, 512, 32], 21).cuda(), synth.radar_cube(2).cuda(), synth.latents([0, 1]).cuda()
+    optimizer = torch.optim.AdamW(m.parameters(), lr=2e-4)
+    scaler = torch.amp.GradScaler()
+    losses = []
+    for it in range(3):
+        loss = _reference_style_loss(m, y, cube, g6, monkeypatch)
+        losses.append(float(loss))
+        scaler.scale(loss).backward()
+        scaler.unscale_(optimizer)
+        norm = torch.nn.utils.clip_grad_norm_(m.parameters(), 10.0)
+        scaler.step(optimizer)
+        scaler.update()
+        optimizer.zero_grad()
+        assert torch.isfinite(norm)
+    print("losses over three reference-style iterations on one batch:", losses)
+    assert losses[2] < losses[0]
+    with torch.no_grad():
+        d = m(x01, torch.tensor(1.0), cube, "radar")
+    assert torch.isfinite(d).all()
+
+
+def _ddp_worker(rank, world, port, out_path):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from rald_amd import models_radar_generation as G, synth
+    m = _edm(2)
+    ddp = torch.nn.parallel.DistributedDataParallel(m, find_unused_parameters=False)      # main_generation.py:157 (gloo: one GPU here)
+    y, cube = synth.normal([1, 512, 32], 50 + rank).cuda(), synth.radar_cube(1, seed=60 + rank).cuda()
+    rnd, noise = synth.normal([1, 1, 1], 70 + rank).cuda(), synth.normal([1, 512, 32], 80 + rank).cuda()
+    sigma = (rnd * 1.2 - 1.2).exp()
+    weight = (sigma ** 2 + 1) / sigma ** 2
+    D = ddp(y + noise * sigma, sigma, cube, "radar")                     # EDMLoss.__call__ with its two draws fixed
+    loss = (weight * (D - y) ** 2).mean()
+    loss.backward()
+    grads = torch.cat([p.grad.flatten() for p in m.parameters()]).cpu()
+    if rank == 0:
+        torch.save({"grads": grads, "loss": float(loss)}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_distributed_data_parallel_world2_averages_the_gradients(tmp_path):
+    """torch DDP (bucketed all-reduce overlapped with backward) around the module, two ranks with different shards: the
+    gradients every rank ends with are the mean of the per-shard gradients computed without DDP."""
+    import torch.multiprocessing as mp
+    from rald_amd import synth
+    out_path = str(tmp_path / "ddp.pt")
+    mp.spawn(_ddp_worker, args=(2, 29611, out_path), nprocs=2, join=True)
+    got = torch.load(out_path, weights_only=True)
+    per_rank = []
+    for rank in range(2):
+        m = _edm(2)
+        y, cube = synth.normal([1, 512, 32], 50 + rank).cuda(), synth.radar_cube(1, seed=60 + rank).cuda()
+        rnd, noise = synth.normal([1, 1, 1], 70 + rank).cuda(), synth.normal([1, 512, 32], 80 + rank).cuda()
+        sigma = (rnd * 1.2 - 1.2).exp()
+        D = m(y + noise * sigma, sigma, cube, "radar")
+        ((sigma ** 2 + 1) / sigma ** 2 * (D - y) ** 2).mean().backward()
+        per_rank.append(torch.cat([p.grad.flatten() for p in m.parameters()]).cpu())
+    mean = (per_rank[0] + per_rank[1]) / 2
+    err = rel_l2(got["grads"], mean)
+    # run-to-run noise of one shard's gradient for scale: the backward (and the encoder's GroupNorm statistics) use fp32 atomics,
+    # and a different summation order moves bf16 roundings downstream
+    m = _edm(2)
+    y, cube = synth.normal([1, 512, 32], 50).cuda(), synth.radar_cube(1, seed=60).cuda()
+    rnd, noise = synth.normal([1, 1, 1], 70).cuda(), synth.normal([1, 512, 32], 80).cuda()
+    sigma = (rnd * 1.2 - 1.2).exp()
+    ((sigma ** 2 + 1) / sigma ** 2 * (m(y + noise * sigma, sigma, cube, "radar") - y) ** 2).mean().backward()
+    noise_level = rel_l2(torch.cat([p.grad.flatten() for p in m.parameters()]).cpu(), per_rank[0])
+    print("DDP gradients vs mean of the per-shard gradients: rel_l2", err, "; run-to-run noise of one shard:", noise_level)
+    assert err < max(5e-3, 3 * noise_level)                             # a wrong averaging factor or a lost bucket is O(1)
