@@ -384,7 +384,7 @@ int Ae::reserve_decode(int B) {
     x_vt = (bf16*)arena.alloc(b * I * M * 2, true);
     x_o = (bf16*)arena.alloc(b * M * I * 2, true);
     x_g = (bf16*)arena.alloc(b * M * 4 * d * 2, true);
-    x_y = (float*)arena.alloc(b * M * 64 * 4, true);
+    x_y = (float*)arena.alloc(b * M * 64 * 4 + b * 4 + 16, true);        // projection [B*M][64] + one |max| word per sample
     for (void** p : dec_ptrs()) RALD_CHECK(*p, "ae: decode workspace allocation failed");
     dec_batch = B;
     return 0;

@@ -136,7 +136,7 @@ int ae_decode_tables(int d, const float* Wq, const float* Wk, const float* ng, c
 template <int VPL>     // d = 64 * VPL
 __global__ __launch_bounds__(256) void ae_ctx_project_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float* __restrict__ t2,
-                                                             float* __restrict__ Y, int rows) {
+                                                             float* __restrict__ Y, unsigned* __restrict__ absmax, int rows, int M) {
     constexpr int D = 64 * VPL;
     __shared__ float xs[4][D];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -167,54 +167,54 @@ __global__ __launch_bounds__(256) void ae_ctx_project_kernel(const float* __rest
         a2 = fmaf(xr[c + 2], t2[(c + 2) * 64 + lane], a2);
         a3 = fmaf(xr[c + 3], t2[(c + 3) * 64 + lane], a3);
     }
-    if (row < rows) Y[(int64_t)row * 64 + lane] = (a0 + a1) + (a2 + a3);
+    const float y = (a0 + a1) + (a2 + a3);
+    if (row < rows) Y[(int64_t)row * 64 + lane] = y;
+    // largest |coefficient| of the sample (the fp16 image's scale): max is order-independent, so the atomic keeps the result
+    // reproducible; non-negative floats compare like their bit patterns
+    float mx = (row < rows && (lane <= SLOT_ONE || lane == SLOT_STD)) ? fabsf(y) : 0.f;
+    mx = wave_max(mx);
+    if (lane == 0 && row < rows) atomicMax(absmax + row / M, __float_as_uint(mx));
 }
 
-// one workgroup per sample: ctx = [ H~ image: M x 128 B | u: M floats | inv_scale, 3 pad floats ]
-__global__ __launch_bounds__(256) void ae_ctx_pack_kernel(const float* __restrict__ Y, unsigned char* __restrict__ ctx, int M, int64_t ctx_stride) {
-    __shared__ float red[4];
-    const float* y = Y + (int64_t)blockIdx.x * M * 64;
-    unsigned char* out = ctx + (int64_t)blockIdx.x * ctx_stride;
-    float mx = 0.f;
-    for (int i = threadIdx.x; i < M * 64; i += 256) {
-        const int k = i & 63;
-        if (k <= SLOT_ONE || k == SLOT_STD) mx = fmaxf(mx, fabsf(y[i]));
-    }
-    mx = wave_max(mx);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+// ctx = [ H~ image: M x 128 B | u: M floats | inv_scale, 3 pad floats ] per sample; 4 latent rows per workgroup
+__global__ __launch_bounds__(256) void ae_ctx_pack_kernel(const float* __restrict__ Y, const unsigned* __restrict__ absmax,
+                                                          unsigned char* __restrict__ ctx, int M, int64_t ctx_stride) {
+    const int b = blockIdx.y;
+    const int l = blockIdx.x * 4 + (threadIdx.x >> 6), k = threadIdx.x & 63;
+    const float* y = Y + (int64_t)b * M * 64;
+    unsigned char* out = ctx + (int64_t)b * ctx_stride;
+    const float mx = __uint_as_float(absmax[b]);
     // power-of-two scale that puts the largest entry into [2^13, 2^14): fp16 keeps 11 bits for everything within 2^-27 of it
     float scale = 1.0f;
     if (mx > 0.f && mx < 3.0e38f) scale = exp2f((float)(13 - ilogbf(mx)));
-    for (int i = threadIdx.x; i < M * 64; i += 256) {
-        const int l = i >> 6, k = i & 63;
-        float v = 0.f;
-        if (k < SLOT_ONE) v = y[i] * scale;
-        else if (k == SLOT_ONE || k == SLOT_ONE + 1) {
-            const float t = y[l * 64 + SLOT_ONE] * scale;
-            const f16 hi = (f16)t;
-            v = k == SLOT_ONE ? (float)hi : t - (float)hi;
-        } else if (k >= SLOT_STD && k <= SLOT_STD + 2) {
-            const float t = y[l * 64 + SLOT_STD] * scale;
-            const f16 hi = (f16)t;
-            v = k == SLOT_STD + 2 ? t - (float)hi : (float)hi;
-        }
-        *reinterpret_cast<f16*>(out + img_off(l, k)) = (f16)v;
+    float v = 0.f;
+    if (k < SLOT_ONE) v = y[l * 64 + k] * scale;
+    else if (k == SLOT_ONE || k == SLOT_ONE + 1) {
+        const float t = y[l * 64 + SLOT_ONE] * scale;
+        const f16 hi = (f16)t;
+        v = k == SLOT_ONE ? (float)hi : t - (float)hi;
+    } else if (k >= SLOT_STD && k <= SLOT_STD + 2) {
+        const float t = y[l * 64 + SLOT_STD] * scale;
+        const f16 hi = (f16)t;
+        v = k == SLOT_STD + 2 ? t - (float)hi : (float)hi;
     }
+    *reinterpret_cast<f16*>(out + img_off(l, k)) = (f16)v;
     float* u = reinterpret_cast<float*>(out + (int64_t)M * 128);
-    for (int l = threadIdx.x; l < M; l += 256) u[l] = y[l * 64 + SLOT_U];
-    if (threadIdx.x == 0) u[M] = 1.0f / scale;
+    if (k == SLOT_U) u[l] = y[l * 64 + SLOT_U];
+    if (l == 0 && k == 0) u[M] = 1.0f / scale;
 }
 
 int ae_ctx_build(const float* x, const float* gamma, const float* beta, const float* t2aug, float* Yscratch, void* ctx, int B, int M, int d,
                  hipStream_t st) {
     RALD_CHECK(d == 256 || d == 512, "ae_ctx_build: dim must be 256 or 512");
+    RALD_CHECK(M % 4 == 0, "ae_ctx_build: num_latents must be a multiple of 4");
     const int rows = B * M;
-    if (d == 256) hipLaunchKernelGGL((ae_ctx_project_kernel<4>), dim3(cdiv(rows, 4)), dim3(256), 0, st, x, gamma, beta, t2aug, Yscratch, rows);
-    else hipLaunchKernelGGL((ae_ctx_project_kernel<8>), dim3(cdiv(rows, 4)), dim3(256), 0, st, x, gamma, beta, t2aug, Yscratch, rows);
+    unsigned* absmax = reinterpret_cast<unsigned*>(Yscratch + (int64_t)rows * 64);      // B words behind the projection (scratch is sized for them)
+    RALD_HIP(hipMemsetAsync(absmax, 0, (size_t)B * 4, st));
+    if (d == 256) hipLaunchKernelGGL((ae_ctx_project_kernel<4>), dim3(cdiv(rows, 4)), dim3(256), 0, st, x, gamma, beta, t2aug, Yscratch, absmax, rows, M);
+    else hipLaunchKernelGGL((ae_ctx_project_kernel<8>), dim3(cdiv(rows, 4)), dim3(256), 0, st, x, gamma, beta, t2aug, Yscratch, absmax, rows, M);
     RALD_HIP(hipGetLastError());
-    hipLaunchKernelGGL(ae_ctx_pack_kernel, dim3(B), dim3(256), 0, st, Yscratch, (unsigned char*)ctx, M, ae_ctx_stride(M));
+    hipLaunchKernelGGL(ae_ctx_pack_kernel, dim3(M / 4, B), dim3(256), 0, st, Yscratch, absmax, (unsigned char*)ctx, M, ae_ctx_stride(M));
     RALD_HIP(hipGetLastError());
     return 0;
 }

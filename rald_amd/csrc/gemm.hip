@@ -369,6 +369,174 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_glds_kernel(GemmArgs a) 
 #endif
 }
 
+#ifdef RALD_PROBE
+// =================================================================================================
+// Persistent form of the 256x256 engine for the GEGLU projection (FF1: the dominant kernel of an NFE).  PROBE builds only
+// (RALD_GEMM_PERSIST=1): measured on MI355X against the plain launch of the same tiles, interleaved in one process
+// (tools/ab_persist.py): FF1 alone 155.1 vs 151.6 us, whole NFE at B = 64 12.75 vs 12.60 ms, with the stagger 12.86 ms - the
+// hardware dispatcher already starts the next workgroup of a CU while the previous one drains its stores, and the tile loop
+// costs the double-buffered fragment registers of the plain kernel's main loop.  Kept as a measured dead end.
+// =================================================================================================
+// One workgroup per CU walks its tiles (virtual block id v = blockIdx.x + j * gridDim.x through the same XCD-aware strip order
+// as above: v % 8 == blockIdx.x % 8, so a workgroup's tiles stay on its XCD's L2).  What the plain launch cannot do:
+//   * the k-loop runs on ACROSS tile boundaries: the first two k-steps of the next tile are issued (LDS-DMA) during the last
+//     two k-steps of the current one and land under its epilogue, so a tile starts with its operands in LDS instead of one
+//     exposed HBM/L2 latency + a workgroup launch;
+//   * the epilogue's transpose patches live in their own 18 KiB of LDS (GEGLU rows are 128 B: 16 x 144 B per wave), so the
+//     two staging buffers stay untouched while the epilogue runs;
+//   * its 8 output stores per wave stay in flight behind counted waits (vmcnt counts stores too): the next tile's first two
+//     hand-overs wait for "all but the youngest 16 / 8" operations, i.e. for their DMA pieces only;
+//   * STAGGER: the workgroups with an odd slot on their XCD start half a tile late, so that from then on half of the CUs
+//     are in their HBM-heavy epilogue while the other half are in the MFMA loop (in a plain launch all 256 CUs run the same
+//     phase at the same time; two independent streams gained 5-7 % from the same effect).
+template <bool STAGGER>
+__global__ __launch_bounds__(512) void gemm_geglu_persist_kernel(GemmArgs a, int ntn, int ntm) {
+    constexpr int BM = 256, BN = 256, BK = 64, WM = 4, WN = 2, WAVES = 8;
+    constexpr int MT = BM / (16 * WM), NT = BN / (16 * WN);
+    constexpr int CA = BM / 8 / WAVES, CB = BN / 8 / WAVES;          // 4 + 4 DMA pieces per wave and stage
+    constexpr int STAGE_BYTES = (BM + BN) * BK * 2;                  // 64 KiB
+    constexpr int PATCH = 16 * (NT * 8 * 2 + 16);                    // 2304 B: one 16-row m-tile of GEGLU output per wave
+    constexpr int NSTORE = MT * 2;                                   // output store instructions per wave and tile (8 rows each)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [2][A tile | B tile] | 8 patches | [2 tiles][8 waves] 512 B of bias
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int nt = ntn * ntm;
+    const int nk = a.K / BK;
+    const int lr = lane >> 3;
+    const int lc = (lane & 7) ^ lr;
+    const int fr = lane & 15, fq = lane >> 4;
+    constexpr int GN = 8;
+    auto tile_origin = [&](int v, int& m0, int& n0) {
+        const int xcd = v & 7, q = nt >> 3, rr = nt & 7;
+        const int tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (v >> 3);
+        int tm, tn;
+        if (ntn % GN == 0) {
+            const int strip = tile / (ntm * GN), within = tile % (ntm * GN);
+            tm = within / GN;
+            tn = strip * GN + within % GN;
+        } else {
+            tm = tile / ntn;
+            tn = tile % ntn;
+        }
+        m0 = tm * BM; n0 = tn * BN;
+    };
+    // one DMA stage: k-step kt of the tile at (m0, n0) into buffer buf.  Full tiles only (host contract: M, N multiples of 256), so
+    // the per-lane part of every source address is a 32-bit element offset fixed for the whole launch (8 VGPRs) and the tile /
+    // k-step part is scalar - the register file has no room for eight 64-bit pointers next to 128 accumulators and 96 fragment
+    // registers (a first version spilled 99 VGPRs to scratch and ran at half the speed of the plain launch).
+    unsigned offA[CA], offB[CB];
+#pragma unroll
+    for (int p = 0; p < CA; ++p) offA[p] = (unsigned)((8 * (wave + WAVES * p) + lr) * (int)a.lda + lc * 8);
+#pragma unroll
+    for (int p = 0; p < CB; ++p) offB[p] = (unsigned)((8 * (wave + WAVES * p) + lr) * (int)a.ldb + lc * 8);
+    auto stage = [&](int m0, int n0, int kt, int buf) {
+        unsigned char* base = smem + buf * STAGE_BYTES;
+        const bf16* sa = a.A + (int64_t)m0 * a.lda + kt * BK;       // scalar
+        const bf16* sb = a.B + (int64_t)n0 * a.ldb + kt * BK;
+#pragma unroll
+        for (int p = 0; p < CA; ++p)
+            __builtin_amdgcn_global_load_lds((glb_void*)(sa + offA[p]), (lds_void*)(base + (wave + WAVES * p) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int p = 0; p < CB; ++p)
+            __builtin_amdgcn_global_load_lds((glb_void*)(sb + offB[p]), (lds_void*)(base + BM * 128 + (wave + WAVES * p) * 1024), 16, 0, 0);
+    };
+    // the wave's 128 bias values of the tile at n0 -> its LDS slot of parity `par` (two 256-byte DMA pieces, 4 bytes per lane)
+    float* const s_bias = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES + WAVES * PATCH);
+    auto stage_bias = [&](int n0, int par) {
+        const float* src = a.bias + n0 + wn * (BN / WN) + lane;
+        float* dst = s_bias + (par * WAVES + wave) * 128;
+        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void*)(src + 64), (lds_void*)(dst + 64), 4, 0, 0);
+    };
+    int v = blockIdx.x;
+    if (v >= nt) return;
+    if (STAGGER && ((blockIdx.x >> 3) & 1)) {
+        // about half a tile of head start for the even slots: a tile is ~5 000 clocks per k-step, s_sleep 127 = 8 128 clocks
+        for (int i = 0; i < (5 * nk + 8) / 16; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    int m0, n0;
+    tile_origin(v, m0, n0);
+    stage_bias(n0, 0);
+    stage(m0, n0, 0, 0);
+    if (nk > 1) stage(m0, n0, 1, 1);
+    bool first = true;
+    int par = 0;
+    for (;;) {
+        const int vn = v + gridDim.x;
+        int m1 = 0, n1 = 0;
+        const bool more = vn < nt;
+        if (more) tile_origin(vn, m1, n1);
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // k-step 0 of this tile (and its bias) must have landed.  Outstanding, oldest first: [bias][stage 0] [stage 1] [the previous
+        // tile's NSTORE stores]
+        if (first) { if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CA + CB) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CA + CB + NSTORE) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            // one 32-deep sub-step: the 4 A fragments at once, the B fragments one n-tile ahead of their 4 MFMAs (24 fragment
+            // registers instead of the 96 of the plain kernel's double-buffered sets: the tile loop needs the difference)
+            auto substep = [&](int kk) {
+                const bf16x8* sA = reinterpret_cast<const bf16x8*>(smem + cur * STAGE_BYTES);
+                const bf16x8* sB = sA + BM * 8;
+                const int chunk = kk * 4 + fq;
+                bf16x8 fa[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int r = wm * (BM / WM) + i * 16 + fr;
+                    fa[i] = sA[r * 8 + (chunk ^ (r & 7))];
+                }
+                const int rb0 = wn * (BN / WN) + fr;
+                bf16x8 fb = sB[rb0 * 8 + (chunk ^ (rb0 & 7))];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    bf16x8 fbn = fb;
+                    if (j + 1 < NT) {
+                        const int r = rb0 + (j + 1) * 16;
+                        fbn = sB[r * 8 + (chunk ^ (r & 7))];
+                    }
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[i], acc[i][j], 0, 0, 0);
+                    fb = fbn;
+                }
+            };
+            substep(0);
+            substep(1);
+            if (kt + 1 < nk) {
+                // k-step kt+1 landed; my reads of buffer `cur` are done.  After the first hand-over of a tile the stores of the
+                // previous tile may still be in flight BEHIND the stage waited for (kt == 0: [stage 1][stores]); later the
+                // only younger operations are DMA pieces issued after them, so everything is waited for.
+                if (kt == 0 && !first) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NSTORE) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (kt + 2 < nk) stage(m0, n0, kt + 2, cur);
+                else if (more) { stage_bias(n1, par ^ 1); stage(m1, n1, kt + 2 - nk, cur); }     // the next tile's bias and k-step 0 (nk even: buffer 0)
+            }
+        }
+        // every wave is done reading the last buffer (nk - 1) & 1 = 1: the next tile's k-step 1 goes there
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (more && nk > 1) stage(m1, n1, 1, 1);
+        gemm_epilogue_lds<MT, NT, EPI_GEGLU>(acc, a, m0 + wm * (BM / WM), n0 + wn * (BN / WN), 0, lane, smem + 2 * STAGE_BYTES + wave * PATCH,
+                                             s_bias + (par * WAVES + wave) * 128);
+        if (!more) break;
+        v = vn; m0 = m1; n0 = n1;
+        first = false;
+        par ^= 1;
+    }
+}
+
+#endif  // RALD_PROBE
+
 // -------------------------------------------------------------------------------------------------
 template <int BM, int BN>
 static int launch_tile(const GemmArgs& a, int epi, hipStream_t st) {
@@ -410,6 +578,33 @@ static int launch_glds(const GemmArgs& a, int epi, hipStream_t st) {
         default: set_error("gemm: bad epilogue"); return 1;
     }
 }
+
+#ifdef RALD_PROBE
+static int launch_geglu_persist(const GemmArgs& a, hipStream_t st) {
+    constexpr int smem = 2 * (256 + 256) * 64 * 2 + 8 * 2304 + 2 * 8 * 512;
+    static int n_cu = 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        RALD_HIP(hipFuncSetAttribute((const void*)gemm_geglu_persist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        RALD_HIP(hipFuncSetAttribute((const void*)gemm_geglu_persist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        int dev = 0;
+        hipDeviceProp_t prop;
+        RALD_HIP(hipGetDevice(&dev));
+        RALD_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount;
+        attr_set = true;
+    }
+    const int ntn = a.N / 256, ntm = a.M / 256;
+    int grid = n_cu - n_cu % 8;                               // a multiple of 8: a workgroup's tiles share its XCD (speed only)
+    if (grid > ntn * ntm) grid = ntn * ntm;
+    if (grid < 8) grid = ntn * ntm < 8 ? ntn * ntm : 8;
+    const bool stagger = RALD_PROBE_ENV("RALD_GEMM_STAGGER", 1) != 0;
+    if (stagger) hipLaunchKernelGGL(gemm_geglu_persist_kernel<true>, dim3(grid), dim3(512), smem, st, a, ntn, ntm);
+    else hipLaunchKernelGGL(gemm_geglu_persist_kernel<false>, dim3(grid), dim3(512), smem, st, a, ntn, ntm);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+#endif
 
 // Host-side shape contract is checked here, before any launch (an out-of-bounds MFMA tile
 // can take the whole node down, so nothing is left to the kernel).
@@ -465,6 +660,12 @@ static int gemm_nt_impl(const GemmArgs& a, int epi, hipStream_t st) {
     }
     if (impl < 0) {
         const int64_t wg256 = (int64_t)(a.M / 256) * (a.N / 256) * nbatch;
+#ifdef RALD_PROBE
+        // probe builds, RALD_GEMM_PERSIST=1: the persistent engine (one workgroup per CU) for GEGLU projections of >= 2 rounds of tiles
+        if (epi == EPI_GEGLU && nbatch == 1 && a.M % 256 == 0 && a.N % 256 == 0 && wg256 >= 512 && a.K % 128 == 0 && !a.out8 &&
+            RALD_PROBE_ENV("RALD_GEMM_PERSIST", 0) != 0)
+            return launch_geglu_persist(a, st);
+#endif
         if (a.M % 256 == 0 && a.N % 256 == 0 && wg256 >= 256) return launch_glds<256, 256, 4, 2, 2>(a, epi, st);
         return launch_glds<128, 128, 2, 2, 2>(a, epi, st);
     }

@@ -11,9 +11,11 @@ namespace rald {
 // the FF1 kernel).  Instead each wave transposes one 16-row m-tile at a time through a private LDS
 // patch (row stride padded by 16 B) and writes it back as whole rows, 16 B per lane: full 128-B
 // lines.  Wave-private, so no workgroup barrier; LDS ops of one wave execute in order.
+// lds_bias (GEGLU only): the wave's NT*16 bias values already in LDS (persistent engine: an ordinary global load next to
+// in-flight LDS-DMA makes hipcc wait vmcnt(0), draining the next tile's prefetch - guide section 5, trap (b))
 template <int MT, int NT, int EPI>
 __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[MT][NT], const GemmArgs& a, int mb, int nb, int64_t coff, int lane,
-                                                  unsigned char* patch) {
+                                                  unsigned char* patch, const float* lds_bias = nullptr) {
     const int fr = lane & 15, fq = lane >> 4;
     constexpr bool F32OUT = (EPI == EPI_F32 || EPI == EPI_RESID);
     constexpr int OC = (EPI == EPI_GEGLU) ? NT * 8 : NT * 16;            // output columns of this wave
@@ -31,8 +33,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[MT][NT], const Ge
 #pragma unroll
             for (int p = 0; p < NT / 2; ++p) {
                 const int nx = nb + 32 * p + 4 * fq;
-                const float4 bx = *reinterpret_cast<const float4*>(a.bias + nx);
-                const float4 bg = *reinterpret_cast<const float4*>(a.bias + nx + 16);
+                const float4 bx = lds_bias ? *reinterpret_cast<const float4*>(lds_bias + 32 * p + 4 * fq) : *reinterpret_cast<const float4*>(a.bias + nx);
+                const float4 bg = lds_bias ? *reinterpret_cast<const float4*>(lds_bias + 32 * p + 4 * fq + 16) : *reinterpret_cast<const float4*>(a.bias + nx + 16);
                 const f32x4 x = acc[i][2 * p], g = acc[i][2 * p + 1];
                 const f32x2 g01 = gelu_poly2(f32x2{g[0] + bg.x, g[1] + bg.y});
                 const f32x2 g23 = gelu_poly2(f32x2{g[2] + bg.z, g[3] + bg.w});

@@ -10,6 +10,14 @@ import torch
 from rald_amd import synth
 
 
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    """The MXFP8 modes belong to the INFERENCE kernels (with gradients enabled EDMPrecond.forward takes the differentiable bf16
+    training route, tests/test_gpu_autograd.py)."""
+    with torch.no_grad():
+        yield
+
+
 def test_mx_oracle_format_identities():
     from oracle import mx_oracle as MX
     x = synth.normal([64, 512], 300) * torch.logspace(-6, 6, 64)[:, None]

@@ -14,6 +14,14 @@ from conftest import load_golden, rel_l2
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    """These tests pin the INFERENCE kernels (the reference's evaluate / sample run under torch.no_grad); with gradients enabled
+    EDMPrecond.forward takes the differentiable training route instead (tests/test_gpu_autograd.py)."""
+    with torch.no_grad():
+        yield
+
+
 def _ae(**kw):
     from rald_amd import models_ae as A, weights
     m = A.create_autoencoder(query_type="mix", **kw)

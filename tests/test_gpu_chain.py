@@ -20,6 +20,14 @@ from conftest import load_golden, rel_l2
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    """These tests pin the INFERENCE kernels (the reference's evaluate / sample run under torch.no_grad); with gradients enabled
+    EDMPrecond.forward takes the differentiable training route instead (tests/test_gpu_autograd.py)."""
+    with torch.no_grad():
+        yield
+
+
 def _edm(depth):
     from rald_amd import config, models_radar_generation as G, weights
     m = G.EDMPrecond(n_latents=512, channels=32, depth=depth, configs=config.shipped_generation_config())
@@ -55,7 +63,10 @@ def test_three_frames_with_recycled_addresses_vs_reference_golden(vae):
     qf = synth.queries(1, 2048, seed=4244).cuda()
     cube_ptrs, tok_ptrs = [], []
     radar_cube = sampled_tokens = None
-    for i, cs in enumerate(g["frame_cube_seeds"]):
+    torch.cuda.empty_cache()
+    for it in range(9):                                              # the three golden frames, three times over
+        i = it % 3
+        cs = g["frame_cube_seeds"][i]
         host = synth.radar_cube(1, seed=int(cs))
         del radar_cube, sampled_tokens                               # what rebinding the loop variables does (engine_generation.py:173-179)
         gc.collect()
@@ -69,11 +80,12 @@ def test_three_frames_with_recycled_addresses_vs_reference_golden(vae):
         print(f"frame {i}: sample rel_l2 {es:.2e}, logits rel_l2 {el:.2e}")
         assert es < 5e-2 and el < 3e-2
         assert torch.equal(again[0], outputs[0, :512])
-    # the hazard was really exercised: the allocator handed a dead frame's block to a later frame (not to the very next one:
-    # the memo entry keeps one frame's tensor alive until the next frame replaces it - that is the fix; a (data_ptr,
-    # _version) key matches there).  Measured on MI355X: cubes at addresses A, B, A.
+    # the hazard was really exercised: the allocator handed a dead frame's block to a later frame holding a DIFFERENT cube (not
+    # necessarily to the very next one: the memo entry keeps one frame's tensor alive until the next frame replaces it - that
+    # is the fix; a (data_ptr, _version) key matches there).  Measured on MI355X: cubes at addresses A, B, A, ...
     print("cube addresses", cube_ptrs, "latent addresses", tok_ptrs)
-    assert len(set(cube_ptrs)) < len(cube_ptrs), cube_ptrs
+    recycled = [(a, b) for a in range(9) for b in range(a + 1, 9) if cube_ptrs[a] == cube_ptrs[b] and a % 3 != b % 3]
+    assert recycled, cube_ptrs
 
 
 def test_forward_and_decode_on_temporaries_never_reuse_a_stale_memo(vae):

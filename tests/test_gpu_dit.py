@@ -13,6 +13,14 @@ import torch
 from conftest import load_golden, rel_l2
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    """These tests pin the INFERENCE kernels (the reference's evaluate / sample run under torch.no_grad); with gradients enabled
+    EDMPrecond.forward takes the differentiable training route instead (tests/test_gpu_autograd.py)."""
+    with torch.no_grad():
+        yield
 TOL_NFE = 1.5e-2
 TOL_SAMPLE = 5e-2
 

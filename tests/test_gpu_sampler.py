@@ -16,6 +16,14 @@ from conftest import load_golden, rel_l2
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    """These tests pin the INFERENCE kernels (the reference's evaluate / sample run under torch.no_grad); with gradients enabled
+    EDMPrecond.forward takes the differentiable training route instead (tests/test_gpu_autograd.py)."""
+    with torch.no_grad():
+        yield
+
+
 def _edm(depth):
     from rald_amd import config, models_radar_generation as G, weights
     m = G.EDMPrecond(n_latents=512, channels=32, depth=depth, configs=config.shipped_generation_config())
