@@ -348,9 +348,21 @@ class EdmTrainer:
                               sigma_data=float(getattr(model, "sigma_data", 1.0)))
         self.enc = EncoderTrainer({k: p for k, p in named.items() if k.startswith("radar_")})
 
+    def _model_range(self):
+        """[lo, hi) of the flat gradient that holds the transformer's gradients (everything under ``model.``): final once
+        ``DitTrainer.forward_backward`` returns, i.e. BEFORE the radar encoder's backward pass - the longest part of the iteration
+        (44 of 80 ms at B = 8) - under which their exchange between the ranks then runs."""
+        if getattr(self, "_mrange", None) is None:
+            base = self.opt.flat_g.data_ptr()
+            los = [((p.grad.data_ptr() - base) // 4, p.numel()) for k, p in self.model.named_parameters() if k.startswith("model.")]
+            self._mrange = (min(l for l, _ in los), max(l + n for l, n in los))
+        return self._mrange
+
     def forward_backward(self, y, cube, rnd_normal, noise):
         tokens = self.enc.forward(cube[..., 0:1].contiguous() if cube.shape[-1] != 1 else cube)
         loss, dtok = self.dit.forward_backward(y, tokens, rnd_normal, noise)
+        if self.reducer is not None:
+            self.reducer.mark_range(*self._model_range())          # the transformer's buckets travel under the encoder's backward
         self.enc.backward(dtok)
         return loss
 
@@ -360,11 +372,10 @@ class EdmTrainer:
         if noise is None:
             noise = torch.randn(y.shape, device=y.device)
         self.opt.zero_grad()
-        loss = self.forward_backward(y, cube, rnd_normal, noise)
-        pre = 1.0
         if self.reducer is not None:
             self.reducer.start()
-            pre = self.reducer.finish()
+        loss = self.forward_backward(y, cube, rnd_normal, noise)
+        pre = self.reducer.finish() if self.reducer is not None else 1.0
         norm = self.opt.clip_grad_norm_(max_norm, pre_scale=pre)
         self.opt.step(ema_rate=ema_rate)
         self.dit.refresh_weights()

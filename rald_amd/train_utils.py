@@ -178,6 +178,8 @@ class GradReducer:
             hi = lo
         self._next = 0
         self._work = []
+        self._done = [False] * len(self.bounds)
+        self._covered: List[Tuple[int, int]] = []
 
     @property
     def world(self) -> int:
@@ -185,22 +187,45 @@ class GradReducer:
 
     def start(self) -> None:
         self._next, self._work = 0, []
+        self._done = [False] * len(self.bounds)
+        self._covered = []
+
+    def _launch(self, i: int) -> None:
+        a, b = self.bounds[i]
+        if self.world > 1:
+            self._work.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._done[i] = True
+
+    def mark_range(self, lo: int, hi: int) -> int:
+        """Elements [lo, hi) of the flat gradient are final (a transformer block's parameters, the encoder's ...): every
+        not-yet-launched bucket that now lies entirely inside finished territory is launched.  The backward pass of EdmTrainer
+        finishes the blocks from the last to the first and the radar encoder (which sits at the END of the flat buffer) last,
+        so the finished region is a union of intervals, not a suffix.  Returns how many buckets were launched."""
+        ivs = sorted(self._covered + [(int(lo), int(hi))])
+        merged: List[Tuple[int, int]] = []
+        for a, b in ivs:
+            if merged and a <= merged[-1][1]:
+                merged[-1] = (merged[-1][0], max(merged[-1][1], b))
+            else:
+                merged.append((a, b))
+        self._covered = merged
+        launched = 0
+        for i, (a, b) in enumerate(self.bounds):
+            if not self._done[i] and any(ca <= a and b <= cb for ca, cb in merged):
+                self._launch(i)
+                launched += 1
+        return launched
 
     def mark_ready(self, lo: int) -> int:
         """Launch every not-yet-launched bucket that lies entirely at or above element ``lo``;
         returns how many were launched."""
-        launched = 0
-        while self._next < len(self.bounds) and self.bounds[self._next][0] >= lo:
-            a, b = self.bounds[self._next]
-            if self.world > 1:
-                self._work.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-            self._next += 1
-            launched += 1
-        return launched
+        return self.mark_range(lo, self.flat.numel())
 
     def finish(self) -> float:
         """Launch what is left, wait for everything; returns the pre_scale (1/world) for the optimizer."""
-        self.mark_ready(0)
+        for i in range(len(self.bounds)):
+            if not self._done[i]:
+                self._launch(i)
         for w in self._work:
             w.wait()
         self._work = []

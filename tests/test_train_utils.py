@@ -66,7 +66,14 @@ def _reduce_worker(rank, world, port, q):
     red.start()
     launched = [red.mark_ready(n), red.mark_ready(n - 16384 - 5), red.mark_ready(7000), red.mark_ready(7000)]
     pre = red.finish()
-    q.put((rank, launched, pre, flat.numpy().copy()))
+    # interval form (EdmTrainer: the transformer's gradients are final before the encoder's, which sit at the END of the buffer):
+    # a bucket leaves as soon as a union of finished ranges covers it, in any order, and exactly once
+    flat2 = synth.normal([n], 80 + rank)
+    red2 = GradReducer(flat2, bucket_bytes=16384 * 4)
+    red2.start()
+    launched += [red2.mark_range(0, 100), red2.mark_range(100, 7260), red2.mark_range(n - 5000, n), red2.mark_range(7000, n - 5000), red2.mark_range(0, n)]
+    red2.finish()
+    q.put((rank, launched, pre, flat.numpy().copy(), flat2.numpy().copy()))
     dist.destroy_process_group()
 
 
@@ -80,10 +87,12 @@ def test_bucketed_gradient_allreduce_gloo_world2():
     res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
     [p.join(timeout=60) for p in procs]
     want = (synth.normal([10007 * 4], 70) + synth.normal([10007 * 4], 71)).numpy()
-    for rank, launched, pre, flat in res:
-        assert launched == [0, 1, 1, 0]                       # a bucket goes out only once it is complete
+    want2 = (synth.normal([10007 * 4], 80) + synth.normal([10007 * 4], 81)).numpy()
+    for rank, launched, pre, flat, flat2 in res:
+        assert launched == [0, 1, 1, 0, 0, 1, 0, 2, 0]        # a bucket goes out only once it is complete, whatever the order of the ranges
         assert pre == 0.5
         assert np.array_equal(flat, want)                     # SUM over ranks, every element exactly once
+        assert np.array_equal(flat2, want2)
 
 
 @pytest.mark.gpu
