@@ -331,6 +331,22 @@ int rald_op_ae_decode_tables(int32_t dim, const float* wq, const float* wk, cons
                              const float* bpe, const float* wfold, float* t2aug_out, uint16_t* l_img_out);
 int rald_op_ae_decode_queries_nw(rald_ae* h, const void* ctx, const float* queries, int32_t batch, int64_t n_queries, float* out_logits,
                                  int32_t waves_per_workgroup, void* stream);
+/* Folded encoder (KLAutoEncoder.encode :351-399; rald_amd/csrc/ae_encode.hip): both attentions of the latent queries over the
+ * input points run with ONE fp16 row of 52 Fourier features per point as key and value (head dim 64).
+ * _tables: the weight-only tables, computed on the HOST in double (no GPU needed).  in[18] = host fp32 tensors in the reference's
+ *   layouts: point_embed.mlp weight [d,51], bias [d]; d_latents [M,d]; mix_attn_layer norm weight, bias [d], to_q [I,d], to_kv [2I,d],
+ *   to_out weight [d,I], bias [d]; s_latents (mix) or latents (learnable) [M,d]; query_proj weight [d,d], bias [d];
+ *   cross_attend_blocks.0 norm_context weight, bias [d], to_q [d,d], to_kv [2d,d], to_out weight [d,d], bias [d]   (I = heads*64; entries
+ *   2-8, 10, 11 may be null when mix == 0).  out[7] (any may be null) = variance factor [52,52], mix queries [M,I], T4 [d,I], X0 [M,d],
+ *   T1 [d,64], T3 [d,64], c3 [d] - see ae_encode.hip for what each multiplies.
+ * _features: F, G fp16 [batch][rows_per_sample][64] from pc [batch][n_points][3] (rows_per_sample = n_points rounded up to 64).
+ * rald_op_attention_f16kv: the attention kernel's fp16 form on such rows (fp32 queries already times scale*log2(e); ksplit < 0 = pick;
+ *   scratch = rald_op_attention_split_scratch_bytes(16, ...) when the keys may be split). */
+int rald_op_ae_encode_tables(int32_t dim, int32_t num_latents, int32_t heads, int32_t mix, const float* const* in, float* const* out);
+int rald_op_ae_enc_features(const float* pc, const float* basis, const float* var_factor, void* F_f16, void* G_f16, int32_t batch, int32_t n_points,
+                            int32_t rows_per_sample, void* stream);
+int rald_op_attention_f16kv(const float* Q, int64_t ldq, int64_t strideQ, const void* KV_f16, void* O_bf16, int64_t ldo, int64_t strideO, int32_t nq,
+                            int32_t nk, int32_t k_rows, int32_t heads, int32_t batch, int32_t ksplit, void* scratch, void* stream);
 /* MXFP8 (OCP microscaling: e4m3 elements + one e8m0 scale per 32 consecutive K elements of a row), the
  * "fp8 MFMA QKV/proj path" of BASELINE config #5.  C = alpha * A . B^T + bias on
  * v_mfma_scale_f32_16x16x128_f8f6f4; epilogue 0 = bf16, 1 = f32, 2 = f32 residual accumulate.  K % 128 == 0;

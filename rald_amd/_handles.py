@@ -262,6 +262,30 @@ def op_attention_vrow(Q: torch.Tensor, K: torch.Tensor, V: torch.Tensor, heads: 
     return O
 
 
+def op_attention_f16kv(Q: torch.Tensor, KV: torch.Tensor, nk: int, heads: int, ksplit: int = -1, shared_q: bool = False) -> torch.Tensor:
+    """Folded-encoder attention: Q fp32 [B,nq,H*64] ([nq,H*64] with shared_q) already times scale*log2(e); KV fp16 [B,k_rows,64] = key AND
+    value row of every head (rows nk.. must be zero) -> O bf16 [B,nq,H*64].  ksplit: -1 pick, 0/1 off, > 1 workgroups per query block."""
+    Bn, k_rows = KV.shape[0], KV.shape[1]
+    nq, HD = Q.shape[-2], Q.shape[-1]
+    assert Q.dtype == torch.float32 and KV.dtype == torch.float16 and Q.is_contiguous() and KV.is_contiguous() and HD == heads * 64
+    O = torch.empty(Bn, nq, HD, device=KV.device, dtype=torch.bfloat16)
+    scratch = torch.empty(lib().rald_op_attention_split_scratch_bytes(max(ksplit, 16), nq, heads, Bn) // 4, device=KV.device, dtype=torch.float32)
+    check(lib().rald_op_attention_f16kv(C.c_void_p(_ptr(Q)), HD, 0 if shared_q else nq * HD, C.c_void_p(_ptr(KV)), C.c_void_p(_ptr(O)), HD, nq * HD,
+                                        nq, nk, k_rows, heads, Bn, ksplit, C.c_void_p(_ptr(scratch)), C.c_void_p(_stream())))
+    return O
+
+
+def op_ae_enc_features(pc: torch.Tensor, basis: torch.Tensor, var_factor: torch.Tensor):
+    """pc [B,P,3] fp32, basis [3,24], var_factor [52,52] -> (F, G) fp16 [B, round_up(P,64), 64] (rald_amd/csrc/ae_encode.hip)."""
+    Bn, P = pc.shape[0], pc.shape[1]
+    Pp = (P + 63) // 64 * 64
+    F = torch.empty(Bn, Pp, 64, device=pc.device, dtype=torch.float16)
+    G = torch.empty_like(F)
+    check(lib().rald_op_ae_enc_features(C.c_void_p(_ptr(_f32c(pc))), C.c_void_p(_ptr(_f32c(basis))), C.c_void_p(_ptr(_f32c(var_factor))),
+                                        C.c_void_p(_ptr(F)), C.c_void_p(_ptr(G)), Bn, P, Pp, C.c_void_p(_stream())))
+    return F, G
+
+
 class AeHandle:
     """rald_ae*: encode / decode_latents / decode_queries of the set-latent autoencoder."""
 

@@ -13,12 +13,16 @@ struct Ae {
     struct AttnW { bf16 *w_q = nullptr, *w_k = nullptr, *w_v = nullptr, *w_o = nullptr; float *b_o = nullptr, *ng = nullptr, *nb = nullptr, *cg = nullptr, *cb = nullptr; };
     struct FfW { bf16 *w1 = nullptr, *w2 = nullptr; float *b1 = nullptr, *b2 = nullptr, *ng = nullptr, *nb = nullptr; };
     struct Layer { bf16 *w_qk = nullptr, *w_v = nullptr, *w_o = nullptr; float *b_o = nullptr, *ng = nullptr, *nb = nullptr; FfW ff; };
-    AttnW cross, mix, dec;
+    AttnW cross, dec;                  // cross: only the query LayerNorm (ng / nb) lives on the device - the rest is folded (ae_encode.hip)
     FfW cross_ff;
     std::vector<Layer> layers;
-    float *basis = nullptr, *b_pe = nullptr, *s_lat = nullptr, *d_lat = nullptr, *b_qp = nullptr, *w_proj = nullptr, *b_proj = nullptr,
-          *b_ml = nullptr, *w_fold = nullptr;
-    bf16 *w_pe = nullptr, *q1 = nullptr, *w_qp = nullptr, *w_ml = nullptr;
+    float *basis = nullptr, *w_proj = nullptr, *b_proj = nullptr, *b_ml = nullptr, *w_fold = nullptr;
+    bf16* w_ml = nullptr;
+    // folded encoder (ae_encode.hip): weight-only tables built at finalize() from host copies of the reference's tensors
+    float *enc_r = nullptr, *enc_q1 = nullptr, *enc_x0 = nullptr, *enc_t1 = nullptr, *enc_c3 = nullptr;
+    bf16 *enc_t4 = nullptr, *enc_t3 = nullptr;
+    std::vector<float> h_lat, h_dlat, h_mix_ng, h_mix_nb, h_mix_wq, h_mix_wkv, h_mix_wo, h_mix_bo, h_wqp, h_bqp, h_cross_cg, h_cross_cb, h_cross_wq,
+        h_cross_wkv, h_cross_wo, h_cross_bo;
     // streaming query decoder (ae_decode.hip): weight-only tables built at finalize()
     float* t2aug = nullptr;            // [d][64] fp32: LN_ctx(x) . t2aug = per-latent score coefficients (slot order) | h0 | hb | u
     unsigned short* l_img = nullptr;   // [64][64] fp16 image: |L.f~|^2 = variance of the query embedding
@@ -32,13 +36,12 @@ struct Ae {
     int64_t ws_generation = 0;   // bumped by every workspace reallocation (captured hipGraphs point into the workspace)
     // encode workspace
     int enc_batch = 0;
-    bf16 *e_feat = nullptr, *e_emb16 = nullptr, *e_embn16 = nullptr, *e_k = nullptr, *e_vt = nullptr, *e_o = nullptr, *e_xq = nullptr,
-         *e_h = nullptr, *e_q2 = nullptr, *e_p = nullptr, *e_g = nullptr;
-    float *e_emb32 = nullptr, *e_dq = nullptr, *e_x = nullptr, *e_s = nullptr, *e_ml = nullptr;
-    float* e_part = nullptr;   // key-split partials of the mix attention at small batch (attention.hip)
+    unsigned short *e_f = nullptr, *e_gk = nullptr;   // fp16 feature rows per point: F (mix layer) and G = rstd.F (cross_attend), [B][Pp][64]
+    bf16 *e_o = nullptr, *e_o2 = nullptr, *e_h = nullptr, *e_g = nullptr;
+    float *e_x = nullptr, *e_q2 = nullptr, *e_ml = nullptr;
+    float* e_part = nullptr;   // key-split partials of the two attentions at small batch (attention.hip)
     std::vector<void**> enc_ptrs() {
-        return {(void**)&e_feat, (void**)&e_emb16, (void**)&e_embn16, (void**)&e_k, (void**)&e_vt, (void**)&e_o, (void**)&e_xq, (void**)&e_h,
-                (void**)&e_q2, (void**)&e_p, (void**)&e_g, (void**)&e_emb32, (void**)&e_dq, (void**)&e_x, (void**)&e_s, (void**)&e_ml, (void**)&e_part};
+        return {(void**)&e_f, (void**)&e_gk, (void**)&e_o, (void**)&e_o2, (void**)&e_h, (void**)&e_g, (void**)&e_x, (void**)&e_q2, (void**)&e_ml, (void**)&e_part};
     }
     // latent-stack workspace
     int dec_batch = 0;
@@ -51,6 +54,7 @@ struct Ae {
 
     int create();
     int load_attn(AttnW& a, int inner, const std::string& t, const float* data, int64_t nelem, bool* handled);
+    int load_folded_attn(bool is_mix, const std::string& t, const float* data, int64_t nelem, bool* handled);
     int load_ff(FfW& f, const std::string& t, const float* data, int64_t nelem, bool* handled);
     int load_weight(const std::string& name, const float* data, int64_t nelem);
     int finalize();

@@ -3,6 +3,7 @@
 //   encode          :351-405   PointEmbed -> mix query (8x64-head attention over the P points,
 //                              no residual) -> query_proj -> 1-head d=dim cross-attention over the
 //                              points + residual -> GEGLU FF + residual -> mean/logvar -> posterior
+//                              (both attentions folded onto the points' 52 Fourier features: ae_encode.hip)
 //   decode_latents  :410-414   proj -> depth x (self-attention, GEGLU FF), then the decoder context
 //   decode_queries  :417-424   PointEmbed(queries) -> 1-head cross-attention over the latents -> Linear(dim,1)
 //
@@ -42,8 +43,6 @@ int Ae::create() {
     auto B16 = [&](size_t n) { return (bf16*)arena.alloc(n * 2, true); };
     auto F32 = [&](size_t n) { return (float*)arena.alloc(n * 4, true); };
     basis = F32(72);
-    w_pe = B16((size_t)d * 64);
-    b_pe = F32(d);
     auto mk_attn = [&](AttnW& a, int inner, bool ctx_norm) {
         a.w_q = B16((size_t)inner * d); a.w_k = B16((size_t)inner * d); a.w_v = B16((size_t)inner * d);
         a.w_o = B16((size_t)d * inner); a.b_o = F32(d); a.ng = F32(d); a.nb = F32(d);
@@ -53,9 +52,8 @@ int Ae::create() {
         f.w1 = B16((size_t)8 * d * d); f.b1 = F32((size_t)8 * d); f.w2 = B16((size_t)d * 4 * d); f.b2 = F32(d);
         f.ng = F32(d); f.nb = F32(d);
     };
-    mk_attn(cross, d, true);
+    cross.ng = F32(d); cross.nb = F32(d);
     mk_ff(cross_ff);
-    if (mixq) mk_attn(mix, I, false);
     mk_attn(dec, d, true);
     layers.resize(c.depth);
     for (auto& l : layers) {
@@ -64,12 +62,9 @@ int Ae::create() {
         l.ng = F32(d); l.nb = F32(d);
         mk_ff(l.ff);
     }
-    s_lat = F32((size_t)M * d);                       // 'learnable': latents.weight
-    if (mixq) {
-        d_lat = F32((size_t)M * d);
-        q1 = B16((size_t)M * I);
-        w_qp = B16((size_t)d * d); b_qp = F32(d);
-    }
+    enc_r = F32(52 * 52); enc_x0 = F32((size_t)M * d); enc_t1 = F32((size_t)d * 64); enc_c3 = F32(d);
+    enc_t3 = B16((size_t)d * 64);
+    if (mixq) { enc_q1 = F32((size_t)M * I); enc_t4 = B16((size_t)d * I); }
     w_proj = F32((size_t)d * L); b_proj = F32(d);
     w_ml = B16((size_t)2 * L * d); b_ml = F32((size_t)2 * L);
     t2aug = F32((size_t)d * 64);
@@ -132,6 +127,23 @@ int Ae::load_attn(AttnW& a, int inner, const std::string& t, const float* data, 
     return 0;
 }
 
+// mix_attn_layer / cross_attend_blocks.0: kept on the host for the fold at finalize(); only cross_attend's query LayerNorm runs on the device
+int Ae::load_folded_attn(bool is_mix, const std::string& t, const float* data, int64_t nelem, bool* handled) {
+    *handled = true;
+    const int inner = is_mix ? I : d;
+    auto need = [&](int64_t n) -> int { RALD_CHECK(nelem == n, "ae: size mismatch for an encoder attention tensor (" + t + ")"); return 0; };
+    if (t == "fn.to_q.weight") { RALD_TRY(need((int64_t)inner * d)); return fetch_host(is_mix ? h_mix_wq : h_cross_wq, data, nelem); }
+    if (t == "fn.to_kv.weight") { RALD_TRY(need((int64_t)2 * inner * d)); return fetch_host(is_mix ? h_mix_wkv : h_cross_wkv, data, nelem); }
+    if (t == "fn.to_out.weight") { RALD_TRY(need((int64_t)d * inner)); return fetch_host(is_mix ? h_mix_wo : h_cross_wo, data, nelem); }
+    if (t == "fn.to_out.bias") { RALD_TRY(need(d)); return fetch_host(is_mix ? h_mix_bo : h_cross_bo, data, nelem); }
+    if (t == "norm.weight") { RALD_TRY(need(d)); return is_mix ? fetch_host(h_mix_ng, data, nelem) : stager.to_f32(data, cross.ng, 1, d, d, nullptr); }
+    if (t == "norm.bias") { RALD_TRY(need(d)); return is_mix ? fetch_host(h_mix_nb, data, nelem) : stager.to_f32(data, cross.nb, 1, d, d, nullptr); }
+    if (!is_mix && t == "norm_context.weight") { RALD_TRY(need(d)); return fetch_host(h_cross_cg, data, nelem); }
+    if (!is_mix && t == "norm_context.bias") { RALD_TRY(need(d)); return fetch_host(h_cross_cb, data, nelem); }
+    *handled = false;
+    return 0;
+}
+
 int Ae::load_ff(FfW& f, const std::string& t, const float* data, int64_t nelem, bool* handled) {
     *handled = true;
     auto need = [&](int64_t n) -> int { RALD_CHECK(nelem == n, "ae: size mismatch for a feed-forward tensor (" + t + ")"); return 0; };
@@ -155,9 +167,9 @@ int Ae::load_weight(const std::string& name, const float* data, int64_t nelem) {
     bool handled = false;
     int rc = 0, li = -1, sub = -1;
     char tail[128] = {0};
-    if (name.rfind("cross_attend_blocks.0.", 0) == 0) rc = load_attn(cross, d, name.substr(22), data, nelem, &handled);
+    if (name.rfind("cross_attend_blocks.0.", 0) == 0) rc = load_folded_attn(false, name.substr(22), data, nelem, &handled);
     else if (name.rfind("cross_attend_blocks.1.", 0) == 0) rc = load_ff(cross_ff, name.substr(22), data, nelem, &handled);
-    else if (name.rfind("mix_attn_layer.", 0) == 0) rc = load_attn(mix, I, name.substr(15), data, nelem, &handled);
+    else if (name.rfind("mix_attn_layer.", 0) == 0) rc = load_folded_attn(true, name.substr(15), data, nelem, &handled);
     else if (name.rfind("decoder_cross_attn.", 0) == 0) {
         const std::string t = name.substr(19);
         // host copies of the tensors that are folded at finalize()
@@ -192,12 +204,12 @@ int Ae::load_weight(const std::string& name, const float* data, int64_t nelem) {
     } else {
         handled = true;
         if (name == "point_embed.basis") { RALD_TRY(need(72)); RALD_TRY(fetch_host(h_basis, data, nelem)); rc = stager.to_f32(data, basis, 1, 72, 72, nullptr); }
-        else if (name == "point_embed.mlp.weight") { RALD_TRY(need((int64_t)d * 51)); RALD_TRY(fetch_host(h_wpe, data, nelem)); rc = stager.to_bf16(data, w_pe, d, 51, 64, nullptr); }
-        else if (name == "point_embed.mlp.bias") { RALD_TRY(need(d)); RALD_TRY(fetch_host(h_bpe, data, nelem)); rc = stager.to_f32(data, b_pe, 1, d, d, nullptr); }
-        else if (name == "s_latents.weight" || name == "latents.weight") { RALD_TRY(need((int64_t)M * d)); rc = stager.to_f32(data, s_lat, M, d, d, nullptr); }
-        else if (name == "d_latents.weight") { RALD_TRY(need((int64_t)M * d)); rc = stager.to_f32(data, d_lat, M, d, d, nullptr); }
-        else if (name == "query_proj.weight") { RALD_TRY(need((int64_t)d * d)); rc = stager.to_bf16(data, w_qp, d, d, d, nullptr); }
-        else if (name == "query_proj.bias") { RALD_TRY(need(d)); rc = stager.to_f32(data, b_qp, 1, d, d, nullptr); }
+        else if (name == "point_embed.mlp.weight") { RALD_TRY(need((int64_t)d * 51)); rc = fetch_host(h_wpe, data, nelem); }
+        else if (name == "point_embed.mlp.bias") { RALD_TRY(need(d)); rc = fetch_host(h_bpe, data, nelem); }
+        else if (name == "s_latents.weight" || name == "latents.weight") { RALD_TRY(need((int64_t)M * d)); rc = fetch_host(h_lat, data, nelem); }
+        else if (name == "d_latents.weight") { RALD_TRY(need((int64_t)M * d)); rc = fetch_host(h_dlat, data, nelem); }
+        else if (name == "query_proj.weight") { RALD_TRY(need((int64_t)d * d)); rc = fetch_host(h_wqp, data, nelem); }
+        else if (name == "query_proj.bias") { RALD_TRY(need(d)); rc = fetch_host(h_bqp, data, nelem); }
         else if (name == "to_outputs.weight") { RALD_TRY(need(d)); rc = fetch_host(h_out_w, data, nelem); }
         else if (name == "to_outputs.bias") { RALD_TRY(need(1)); rc = fetch_host(h_out_b, data, nelem); }
         else if (name == "proj.weight") { RALD_TRY(need((int64_t)d * L)); rc = stager.to_f32(data, w_proj, d, L, L, nullptr); }
@@ -218,16 +230,22 @@ int Ae::load_weight(const std::string& name, const float* data, int64_t nelem) {
 int Ae::finalize() {
     for (const auto& k : expected) RALD_CHECK(loaded.count(k), "ae: missing key '" + k + "' (strict load)");
     const int M = cfg.num_latents;
-    // (1) the mix layer's query is input-independent: q1 = to_q(LN(d_latents))      (:383-384)
-    if (cfg.query_type == 0) {
-        bf16* tmp = (bf16*)arena.alloc((size_t)M * d * 2, true);
-        RALD_CHECK(tmp, "ae: allocation failed");
-        RALD_TRY(layernorm_mod(d_lat, tmp, M, d, mix.ng, mix.nb, 0, 1 << 30, 0.f, 1e-5f, nullptr));
-        GemmArgs g = gemm_args(tmp, d, mix.w_q, d, q1, I, nullptr, M, I, d);
-        g.alpha = (1.0f / sqrtf((float)cfg.dim_head)) * 1.4426950408889634f;     // q1 carries the softmax scale * log2(e)
-        RALD_TRY(gemm_nt(g, EPI_BF16, nullptr));
-        RALD_HIP(hipDeviceSynchronize());
-        arena.release(tmp);
+    // (1) the folded encoder's weight-only tables (ae_encode.hip), in double on the host
+    {
+        const bool mixq = cfg.query_type == 0;
+        std::vector<float> Rf, Q1, T4, X0, T1, T3, c3;
+        RALD_TRY(ae_encode_tables(d, I, M, cfg.heads, mixq, h_wpe.data(), h_bpe.data(), h_dlat.data(), h_mix_ng.data(), h_mix_nb.data(), h_mix_wq.data(),
+                                  h_mix_wkv.data(), h_mix_wo.data(), h_mix_bo.data(), h_lat.data(), h_wqp.data(), h_bqp.data(), h_cross_cg.data(),
+                                  h_cross_cb.data(), h_cross_wq.data(), h_cross_wkv.data(), h_cross_wo.data(), h_cross_bo.data(), Rf, Q1, T4, X0, T1, T3, c3));
+        RALD_HIP(hipMemcpy(enc_r, Rf.data(), Rf.size() * 4, hipMemcpyHostToDevice));
+        RALD_HIP(hipMemcpy(enc_x0, X0.data(), X0.size() * 4, hipMemcpyHostToDevice));
+        RALD_HIP(hipMemcpy(enc_t1, T1.data(), T1.size() * 4, hipMemcpyHostToDevice));
+        RALD_HIP(hipMemcpy(enc_c3, c3.data(), c3.size() * 4, hipMemcpyHostToDevice));
+        RALD_TRY(stager.to_bf16(T3.data(), enc_t3, d, 64, 64, nullptr));
+        if (mixq) {
+            RALD_HIP(hipMemcpy(enc_q1, Q1.data(), Q1.size() * 4, hipMemcpyHostToDevice));
+            RALD_TRY(stager.to_bf16(T4.data(), enc_t4, d, I, I, nullptr));
+        }
     }
     // (2) decoder folding, in double on the host:
     //     wo' = Wo^T.w_out [d];  w_fold = Wv^T.wo' [d];  c0 = b_o.w_out + b_out;  WqT for G = K.Wq
@@ -271,20 +289,13 @@ int Ae::reserve_encode(int B) {
     for (void** p : enc_ptrs()) if (*p) { arena.release(*p); *p = nullptr; }
     const size_t P = cfg.num_inputs, Pp = round_up(P, 64), M = cfg.num_latents, L = cfg.latent_dim;
     const size_t b = B;
-    e_feat = (bf16*)arena.alloc(b * P * 64 * 2, true);
-    e_emb32 = (float*)arena.alloc(b * P * d * 4, true);
-    e_emb16 = (bf16*)arena.alloc(b * P * d * 2, true);
-    e_embn16 = (bf16*)arena.alloc(b * P * d * 2, true);
-    e_k = (bf16*)arena.alloc(b * Pp * 512 * 2, true);           // K1 [B][Pp][I] then reused as K2 [B][Pp][d] (d <= I)
-    e_vt = (bf16*)arena.alloc(b * 512 * Pp * 2, true);          // Vt1 [B][I][Pp] then Vt2 [B][d][Pp]
-    e_o = (bf16*)arena.alloc(b * M * 512 * 2, true);
-    e_dq = (float*)arena.alloc(b * M * d * 4, true);
-    e_xq = (bf16*)arena.alloc(b * M * d * 2, true);
+    e_f = (unsigned short*)arena.alloc(b * Pp * 64 * 2, true);
+    e_gk = (unsigned short*)arena.alloc(b * Pp * 64 * 2, true);
+    e_o = (bf16*)arena.alloc(b * M * I * 2, true);
+    e_o2 = (bf16*)arena.alloc(b * M * 64 * 2, true);
     e_x = (float*)arena.alloc(b * M * d * 4, true);
+    e_q2 = (float*)arena.alloc(b * M * 64 * 4, true);
     e_h = (bf16*)arena.alloc(b * M * d * 2, true);
-    e_q2 = (bf16*)arena.alloc(b * M * d * 2, true);
-    e_s = (float*)arena.alloc(b * M * Pp * 4, true);
-    e_p = (bf16*)arena.alloc(b * M * Pp * 2, true);
     e_g = (bf16*)arena.alloc(b * M * 4 * d * 2, true);
     e_ml = (float*)arena.alloc(b * M * 2 * L * 4, true);
     e_part = (float*)arena.alloc((size_t)attention_split_scratch_bytes(16, (int)M, cfg.heads, B), true);
@@ -299,61 +310,34 @@ int Ae::encode(const float* pc, int B, const float* eps, float* mean_o, float* l
     RALD_TRY(reserve_encode(B));
     const int P = cfg.num_inputs, Pp = (int)round_up(P, 64), M = cfg.num_latents, L = cfg.latent_dim;
     const int BM = B * M;
-    // ---- PointEmbed (:355)
-    RALD_TRY(point_features(pc, basis, e_feat, (int64_t)B * P, st));
-    GemmArgs pe = gemm_args(e_feat, 64, w_pe, 64, e_emb32, d, b_pe, B * P, d, 64);
-    RALD_TRY(gemm_nt(pe, EPI_F32, st));
-    RALD_TRY(cast_f32_bf16(e_emb32, e_emb16, (int64_t)B * P * d, st));
-    if (cfg.query_type == 1) {
-        // ---- 'learnable' query (:378-379): x = latents.weight for every sample
-        for (int b = 0; b < B; ++b)
-            RALD_HIP(hipMemcpyAsync(e_x + (size_t)b * M * d, s_lat, (size_t)M * d * 4, hipMemcpyDeviceToDevice, st));
-    } else {
-        // ---- mix query: dynamic_query = mix_attn_layer(d_latents, context=pc_embeddings) (:384; context NOT normed)
-        GemmArgs k1 = gemm_args(e_emb16, d, mix.w_k, d, e_k, I, nullptr, P, I, d);
-        k1.batch = B; k1.strideA = (int64_t)P * d; k1.strideC = (int64_t)Pp * I;
-        RALD_TRY(gemm_nt(k1, EPI_BF16, st));
-        GemmArgs v1 = gemm_args(mix.w_v, d, e_emb16, d, e_vt, Pp, nullptr, I, P, d);
-        v1.batch = B; v1.strideB = (int64_t)P * d; v1.strideC = (int64_t)I * Pp;
-        RALD_TRY(gemm_nt(v1, EPI_BF16, st));
-        AttnArgs a1;
-        a1.Q = q1; a1.ldq = I; a1.strideQ = 0;
-        a1.K = e_k; a1.ldk = I; a1.strideK = (int64_t)Pp * I;
-        a1.Vt = e_vt; a1.ldvt = Pp; a1.strideVt = (int64_t)I * Pp;
-        a1.O = e_o; a1.ldo = I; a1.strideO = (int64_t)M * I;
-        a1.nq = M; a1.nk = P; a1.k_rows = Pp; a1.heads = cfg.heads; a1.batch = B; a1.scale = 1.0f / sqrtf((float)cfg.dim_head); a1.q_prescaled = 1;
-        a1.ksplit = attention_pick_ksplit(M, P, cfg.heads, B);            // 512 queries x 10 000 keys: 32 workgroups at B = 1 without it
-        a1.part = e_part;
-        RALD_TRY(attention_d64(a1, st));
-        GemmArgs o1 = gemm_args(e_o, I, mix.w_o, I, e_dq, d, mix.b_o, BM, d, I);
-        RALD_TRY(gemm_nt(o1, EPI_F32, st));
-        // ---- x = query_proj(static_query + dynamic_query)                            (:385-386)
-        RALD_TRY(add_bcast_cast(s_lat, e_dq, e_xq, (int64_t)M * d, B, st));
-        GemmArgs qp = gemm_args(e_xq, d, w_qp, d, e_x, d, b_qp, BM, d, d);
-        RALD_TRY(gemm_nt(qp, EPI_F32, st));
+    // ---- per point: the Fourier features of PointEmbed (:355) and 1/std of its embedding, as fp16 key = value rows
+    RALD_TRY(ae_enc_features(pc, basis, enc_r, e_f, e_gk, B, P, Pp, st));
+    auto folded_attention = [&](const float* Q, int64_t ldq, int64_t strideQ, const unsigned short* KV, bf16* O, int64_t ldo, int heads) -> int {
+        AttnArgs a;
+        a.Q = nullptr; a.Qf = Q; a.ldq = ldq; a.strideQ = strideQ; a.f16 = 1;
+        a.K = (const bf16*)KV; a.ldk = 64; a.strideK = (int64_t)Pp * 64;
+        a.Vt = nullptr; a.ldvt = 0; a.strideVt = 0;
+        a.V = (const bf16*)KV; a.ldv = 64; a.strideV = (int64_t)Pp * 64; a.v_padded = 1;
+        a.hsk = 0;                                                         // every head reads the same 64 feature columns
+        a.O = O; a.ldo = ldo; a.strideO = (int64_t)M * ldo;
+        a.nq = M; a.nk = P; a.k_rows = Pp; a.heads = heads; a.batch = B; a.scale = 1.f; a.q_prescaled = 1;
+        a.ksplit = attention_pick_ksplit(M, P, heads, B);                  // 512 queries x 10 000 keys: few workgroups at small B without it
+        a.part = e_part;
+        return attention_d64(a, st);
+    };
+    const float* xin = nullptr;
+    if (cfg.query_type == 0) {
+        // ---- mix query (:380-386): O1[m][64h + j] = sum_p softmax_p(Q1_h[m].f_p) f_p[j];  x = X0 + O1.T4^T
+        RALD_TRY(folded_attention(enc_q1, I, 0, e_f, e_o, I, cfg.heads));
+        GemmArgs g4 = gemm_args(e_o, I, enc_t4, I, e_x, d, nullptr, BM, d, I);
+        RALD_TRY(gemm_nt(g4, EPI_F32, st));
+        xin = e_x;
     }
-    // ---- x = cross_attn(x, context=pc_embeddings) + x   (1 head x dim, both normed) (:395)
-    RALD_TRY(layernorm_mod(e_emb32, e_embn16, B * P, d, cross.cg, cross.cb, 0, 1 << 30, 0.f, 1e-5f, st));
-    RALD_TRY(layernorm_mod(e_x, e_h, BM, d, cross.ng, cross.nb, 0, 1 << 30, 0.f, 1e-5f, st));
-    GemmArgs q2 = gemm_args(e_h, d, cross.w_q, d, e_q2, d, nullptr, BM, d, d);
-    RALD_TRY(gemm_nt(q2, EPI_BF16, st));
-    GemmArgs k2 = gemm_args(e_embn16, d, cross.w_k, d, e_k, d, nullptr, P, d, d);
-    k2.batch = B; k2.strideA = (int64_t)P * d; k2.strideC = (int64_t)Pp * d;
-    RALD_TRY(gemm_nt(k2, EPI_BF16, st));
-    GemmArgs v2 = gemm_args(cross.w_v, d, e_embn16, d, e_vt, Pp, nullptr, d, P, d);
-    v2.batch = B; v2.strideB = (int64_t)P * d; v2.strideC = (int64_t)d * Pp;
-    RALD_TRY(gemm_nt(v2, EPI_BF16, st));
-    // S = q.k^T * dim^-1/2, materialised in fp32 ([M x P] per sample is only 20 MB): softmax -> P bf16 -> P.V
-    GemmArgs s = gemm_args(e_q2, d, e_k, d, e_s, Pp, nullptr, M, P, d);
-    s.batch = B; s.strideA = (int64_t)M * d; s.strideB = (int64_t)Pp * d; s.strideC = (int64_t)M * Pp;
-    s.alpha = 1.0f / sqrtf((float)d);
-    RALD_TRY(gemm_nt(s, EPI_F32, st));
-    RALD_TRY(softmax_rows(e_s, Pp, e_p, Pp, BM, P, st));
-    GemmArgs pv = gemm_args(e_p, Pp, e_vt, Pp, e_o, d, nullptr, M, d, Pp);
-    pv.batch = B; pv.strideA = (int64_t)M * Pp; pv.strideB = (int64_t)d * Pp; pv.strideC = (int64_t)M * d;
-    RALD_TRY(gemm_nt(pv, EPI_BF16, st));
-    GemmArgs o2 = gemm_args(e_o, d, cross.w_o, d, e_x, d, cross.b_o, BM, d, d);
-    RALD_TRY(gemm_nt(o2, EPI_RESID, st));
+    // ---- x = cross_attn(x, context=pc_embeddings) + x (:395): Q' = LN(x).T1; O' = softmax(Q'.g_p) g_p; x += O'.T3^T + c3
+    RALD_TRY(ae_enc_qproj(xin, enc_x0, e_x, cross.ng, cross.nb, enc_t1, e_q2, BM, M, d, st));
+    RALD_TRY(folded_attention(e_q2, 64, (int64_t)M * 64, e_gk, e_o2, 64, 1));
+    GemmArgs g3 = gemm_args(e_o2, 64, enc_t3, 64, e_x, d, enc_c3, BM, d, 64);
+    RALD_TRY(gemm_nt(g3, EPI_RESID, st));
     // ---- x = cross_ff(x) + x                                                      (:396)
     RALD_TRY(layernorm_mod(e_x, e_h, BM, d, cross_ff.ng, cross_ff.nb, 0, 1 << 30, 0.f, 1e-5f, st));
     GemmArgs f1 = gemm_args(e_h, d, cross_ff.w1, d, e_g, 4 * d, cross_ff.b1, BM, 8 * d, d);

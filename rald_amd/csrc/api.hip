@@ -424,6 +424,37 @@ int rald_op_attention_vrow(const void* Q, int64_t ldq, int64_t strideQ, const vo
     a.nq = nq; a.nk = nk; a.k_rows = nk; a.heads = heads; a.batch = batch; a.scale = scale; a.q_prescaled = 0;
     return attention_d64(a, (hipStream_t)stream);
 }
+// fp16 shared-key form (the folded encoder attentions, ae_encode.hip): fp32 pre-scaled queries [batch?][nq][heads*64], ONE fp16 row per key
+// [batch][k_rows][64] that is key and value of every head; rows nk .. k_rows-1 must be zero
+int rald_op_attention_f16kv(const float* Q, int64_t ldq, int64_t strideQ, const void* KV_f16, void* O_bf16, int64_t ldo, int64_t strideO, int32_t nq,
+                            int32_t nk, int32_t k_rows, int32_t heads, int32_t batch, int32_t ksplit, void* scratch, void* stream) {
+    RALD_CHECK(Q && KV_f16 && O_bf16, "rald_op_attention_f16kv: null pointer");
+    AttnArgs a;
+    a.Q = nullptr; a.Qf = Q; a.ldq = ldq; a.strideQ = strideQ; a.f16 = 1;
+    a.K = (const bf16*)KV_f16; a.ldk = 64; a.strideK = (int64_t)k_rows * 64;
+    a.Vt = nullptr; a.ldvt = 0; a.strideVt = 0; a.V = (const bf16*)KV_f16; a.ldv = 64; a.strideV = (int64_t)k_rows * 64; a.v_padded = 1; a.hsk = 0;
+    a.O = (bf16*)O_bf16; a.ldo = ldo; a.strideO = strideO;
+    a.nq = nq; a.nk = nk; a.k_rows = k_rows; a.heads = heads; a.batch = batch; a.scale = 1.f; a.q_prescaled = 1;
+    a.ksplit = ksplit >= 0 ? ksplit : attention_pick_ksplit(nq, nk, heads, batch);
+    a.part = (float*)scratch;
+    return attention_d64(a, (hipStream_t)stream);
+}
+int rald_op_ae_enc_features(const float* pc, const float* basis, const float* var_factor, void* F_f16, void* G_f16, int32_t batch, int32_t n_points,
+                            int32_t rows_per_sample, void* stream) {
+    return ae_enc_features(pc, basis, var_factor, F_f16, G_f16, batch, n_points, rows_per_sample, (hipStream_t)stream);
+}
+int rald_op_ae_encode_tables(int32_t dim, int32_t num_latents, int32_t heads, int32_t mix, const float* const* in, float* const* out) {
+    RALD_CHECK(in && out && dim >= 64 && num_latents >= 1 && heads >= 1, "rald_op_ae_encode_tables: bad argument");
+    for (int i = 0; i < 18; ++i) RALD_CHECK(in[i] || (!mix && i >= 2 && i <= 11 && i != 9), "rald_op_ae_encode_tables: null input tensor");
+    const int I = heads * 64;
+    std::vector<float> Rf, Q1, T4, X0, T1, T3, c3;
+    RALD_TRY(rald::ae_encode_tables(dim, I, num_latents, heads, mix != 0, in[0], in[1], in[2], in[3], in[4], in[5], in[6], in[7], in[8], in[9], in[10], in[11],
+                                    in[12], in[13], in[14], in[15], in[16], in[17], Rf, Q1, T4, X0, T1, T3, c3));
+    const std::vector<float>* v[7] = {&Rf, &Q1, &T4, &X0, &T1, &T3, &c3};
+    for (int i = 0; i < 7; ++i)
+        if (out[i] && !v[i]->empty()) memcpy(out[i], v[i]->data(), v[i]->size() * 4);
+    return 0;
+}
 int rald_op_attn_self_proj(const void* qkv_bf16, int64_t ld, const void* Wo_bf16, float* part, int32_t n_latents, int32_t heads, int32_t batch,
                            void* stream) {
     return attn_self_proj((const bf16*)qkv_bf16, ld, (const bf16*)Wo_bf16, part, n_latents, heads, batch, (hipStream_t)stream);

@@ -54,7 +54,17 @@ __device__ __forceinline__ float fast_exp2(float x) {
 #else
 #define RALD_ATTN_ATTR
 #endif
-template <bool PRESCALED, bool VROW>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// F16: K / V hold fp16 and the queries arrive in fp32 (a.Qf) - the folded set-encoder attention (ae_encode.hip), whose keys are
+// Fourier features: 11 mantissa bits instead of 8 on operands that are bounded by construction.  Fragments stay `bf16x8` bit
+// containers; only the conversions and the MFMA opcode differ.
+template <bool F16>
+__device__ __forceinline__ f32x16 attn_mfma(const bf16x8& x, const bf16x8& y, const f32x16& c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+}
+
+template <bool PRESCALED, bool VROW, bool F16 = false>
 __global__ __launch_bounds__(256) RALD_ATTN_ATTR void attention_d64_kernel(AttnArgs a) {
     constexpr int TILE_BYTES = 64 * 128;                       // 64 rows x 128 B (K: keys x d, Vt: d x keys)
     constexpr int NST = RALD_ATTN_STAGES;
@@ -90,7 +100,7 @@ __global__ __launch_bounds__(256) RALD_ATTN_ATTR void attention_d64_kernel(AttnA
     int q0 = (qblk * 4 + wave) * 32;
     const bool active = q0 < a.nq;                             // a ragged last workgroup still helps staging
     if (!active) q0 = a.nq - 32;
-    const bf16* Q = a.Q + (int64_t)b * a.strideQ + (int64_t)(q0 + r) * a.ldq + h * 64 + 8 * hf;
+    const int64_t qoff = (int64_t)b * a.strideQ + (int64_t)(q0 + r) * a.ldq + h * 64 + 8 * hf;
 
     // DMA sources: piece p of this wave = tile rows 8*(wave + 4p) .. +7; lane -> (row l>>3, phys chunk l&7)
     // LDS swizzle: physical 16-byte chunk = logical chunk ^ ((row >> 1) & 7).  With 128-byte rows the
@@ -103,15 +113,15 @@ __global__ __launch_bounds__(256) RALD_ATTN_ATTR void attention_d64_kernel(AttnA
     for (int p = 0; p < 2; ++p) {
         const int row = 8 * (wave + 4 * p) + lr;
         const int lc = (lane & 7) ^ ((row >> 1) & 7);
-        gK[p] = a.K + (int64_t)b * a.strideK + (int64_t)row * a.ldk + h * 64 + lc * 8;
+        gK[p] = a.K + (int64_t)b * a.strideK + (int64_t)row * a.ldk + h * a.hsk + lc * 8;
         if constexpr (VROW) {
             // V tile = [64 keys][64 d] like K, but read only through transposed 4x16 blocks (4 consecutive keys x 16 d):
             // swizzle chunk ^ 4 on rows with bit 1 set, so that the two row pairs of a block fall into different halves of
             // the 128-byte row (rows r and r+2 share a bank row)
             const int lcv = (lane & 7) ^ ((row & 2) << 1);
-            gV[p] = a.V + (int64_t)b * a.strideV + (int64_t)row * a.ldv + h * 64 + lcv * 8;
+            gV[p] = a.V + (int64_t)b * a.strideV + (int64_t)row * a.ldv + h * a.hsk + lcv * 8;
         } else {
-            gV[p] = a.Vt + (int64_t)b * a.strideVt + (int64_t)(h * 64 + row) * a.ldvt + lc * 8;
+            gV[p] = a.Vt + (int64_t)b * a.strideVt + (int64_t)(h * a.hsk + row) * a.ldvt + lc * 8;
         }
     }
     auto stage = [&](int j0, int buf) {
@@ -125,7 +135,15 @@ __global__ __launch_bounds__(256) RALD_ATTN_ATTR void attention_d64_kernel(AttnA
 
     bf16x8 qf[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(Q + 16 * s);
+    for (int s = 0; s < 4; ++s) {
+        if constexpr (F16) {
+            const float4 x0 = *reinterpret_cast<const float4*>(a.Qf + qoff + 16 * s), x1 = *reinterpret_cast<const float4*>(a.Qf + qoff + 16 * s + 4);
+            f16x8 f;
+            f[0] = (_Float16)x0.x; f[1] = (_Float16)x0.y; f[2] = (_Float16)x0.z; f[3] = (_Float16)x0.w;
+            f[4] = (_Float16)x1.x; f[5] = (_Float16)x1.y; f[6] = (_Float16)x1.z; f[7] = (_Float16)x1.w;
+            qf[s] = __builtin_bit_cast(bf16x8, f);
+        } else qf[s] = *reinterpret_cast<const bf16x8*>(a.Q + qoff + 16 * s);
+    }
 
     f32x16 o0, o1;
 #pragma unroll
@@ -178,7 +196,7 @@ __global__ __launch_bounds__(256) RALD_ATTN_ATTR void attention_d64_kernel(AttnA
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 if (!(RALD_ATTN_ABLATE & 16) || s == 0) kf = *reinterpret_cast<const bf16x8*>(sK + krow * 128 + (((2 * s + hf) ^ ((krow >> 1) & 7)) << 4));
-                st[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[u], 0, 0, 0);
+                st[u] = attn_mfma<F16>(kf, qf[s], st[u]);
             }
         }
 #if RALD_ATTN_PRIO
@@ -262,8 +280,15 @@ __global__ __launch_bounds__(256) RALD_ATTN_ATTR void attention_d64_kernel(AttnA
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 bf16x8 pf;
+                if constexpr (F16) {
+                    f16x8 ph;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[u][8 * s + j];
+                    for (int j = 0; j < 8; ++j) ph[j] = (_Float16)st[u][8 * s + j];
+                    pf = __builtin_bit_cast(bf16x8, ph);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (bf16)st[u][8 * s + j];
+                }
                 const int ch = 4 * u + 2 * s;                  // 8-key chunk holding keys 32u+16s .. +7
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
@@ -299,8 +324,8 @@ __global__ __launch_bounds__(256) RALD_ATTN_ATTR void attention_d64_kernel(AttnA
                     if constexpr ((RALD_ATTN_ABLATE & 8) != 0) {
                         if (dt == 0) o0[u * 2 + s] += (float)vf[0] * (float)pf[0] + (float)pf[7];
                         else o1[u * 2 + s] += (float)vf[0] * (float)pf[1] + (float)pf[6];
-                    } else if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o0, 0, 0, 0);
-                    else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o1, 0, 0, 0);
+                    } else if (dt == 0) o0 = attn_mfma<F16>(vf, pf, o0);
+                    else o1 = attn_mfma<F16>(vf, pf, o1);
                 }
             }
     };
@@ -394,10 +419,17 @@ int attention_d64(const AttnArgs& a, hipStream_t st) {
     RALD_CHECK(a.nq % 32 == 0, "attention: nq must be a multiple of 32");
     RALD_CHECK(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldo % 8 == 0, "attention: leading dimensions must be multiples of 8 elements (16-byte rows)");
     RALD_CHECK(a.k_rows >= round_up(a.nk, 64), "attention: K must have rows allocated up to a multiple of 64 keys (the tail tile is staged whole)");
-    RALD_CHECK(((uintptr_t)a.Q % 16 == 0) && ((uintptr_t)a.K % 16 == 0) && ((uintptr_t)a.O % 16 == 0), "attention: pointers must be 16-byte aligned");
+    RALD_CHECK(((uintptr_t)a.K % 16 == 0) && ((uintptr_t)a.O % 16 == 0), "attention: pointers must be 16-byte aligned");
+    RALD_CHECK(a.hsk == 64 || a.hsk == 0, "attention: the heads read K/V 64 columns apart or all the same 64 columns");
     const bool vrow = a.V != nullptr;
+    if (a.f16) {
+        RALD_CHECK(a.Qf && (uintptr_t)a.Qf % 16 == 0 && a.ldq % 4 == 0 && a.q_prescaled && vrow, "attention: the fp16 form takes fp32 pre-scaled queries and a row-major V");
+    } else {
+        RALD_CHECK(a.Q && (uintptr_t)a.Q % 16 == 0, "attention: Q must be 16-byte aligned");
+    }
     if (vrow) {
-        RALD_CHECK(a.Vt == nullptr && a.nk % 64 == 0 && a.ldv % 8 == 0 && (uintptr_t)a.V % 16 == 0, "attention: row-major V needs nk % 64 == 0 and 16-byte rows");
+        RALD_CHECK(a.Vt == nullptr && (a.nk % 64 == 0 || a.v_padded) && a.ldv % 8 == 0 && (uintptr_t)a.V % 16 == 0,
+                   "attention: row-major V needs 16-byte rows and nk % 64 == 0 (or rows zero-filled up to k_rows: v_padded)");
     } else {
         RALD_CHECK(a.Vt && a.ldvt % 8 == 0 && (uintptr_t)a.Vt % 16 == 0, "attention: Vt must be 16-byte aligned with 16-byte rows");
         RALD_CHECK(a.ldvt >= round_up(a.nk, 64), "attention: Vt rows must be padded (finite values) to a multiple of 64 keys");
@@ -406,7 +438,8 @@ int attention_d64(const AttnArgs& a, hipStream_t st) {
     if (ksplit > 1) RALD_CHECK(a.part && ksplit <= 64 && (uintptr_t)a.part % 8 == 0, "attention: key split needs a scratch buffer (attention_split_scratch_bytes)");
     RALD_CHECK((int64_t)cdiv(a.nq, 128) * ksplit * a.heads * a.batch < (1ll << 31), "attention: too many workgroups");
     dim3 grid(cdiv(a.nq, 128) * ksplit * a.heads * a.batch);
-    if (a.q_prescaled) {
+    if (a.f16) hipLaunchKernelGGL((attention_d64_kernel<true, true, true>), grid, dim3(256), 0, st, a);
+    else if (a.q_prescaled) {
         if (vrow) hipLaunchKernelGGL((attention_d64_kernel<true, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((attention_d64_kernel<true, false>), grid, dim3(256), 0, st, a);
     } else {

@@ -92,6 +92,11 @@ struct AttnArgs {
     int k_rows;                                // rows allocated per batch in K (>= round_up(nk,64): the tail tile reads them)
     float scale;                               // softmax scale; ignored when q_prescaled
     int q_prescaled;                           // Q already multiplied by scale*log2(e) (done for free in the producing GEMM's epilogue)
+    // fp16 form (the folded set-encoder attention, ae_encode.hip): K and V point at fp16 data, the queries are fp32 in Qf (same
+    // ldq / strideQ, in elements), converted on load.  Needs q_prescaled and the row-major V.
+    int f16 = 0; const float* Qf = nullptr;
+    int hsk = 64;                              // column offset between the heads' K / V slices; 0 = every head reads the same 64 columns
+    int v_padded = 0;                          // row-major V: rows nk .. k_rows-1 are finite (zero), so nk need not be a multiple of 64
 };
 int attention_d64(const AttnArgs& a, hipStream_t st);
 int attention_pick_ksplit(int nq, int nk, int heads, int batch);
@@ -137,6 +142,16 @@ int add_bcast_cast(const float* a, const float* d, bf16* out, int64_t per_batch,
 int posterior(const float* ml, const float* eps, float* mean_o, float* logvar_o, float* z, float* kl, int B, int rows, int L, hipStream_t st);
 int small_k_linear(const float* in, const float* W, const float* bias, float* out, int M, int K, int N, hipStream_t st);
 
+// ---------------------------------------------------------------- ae_encode.hip (folded encoder attentions)
+int ae_embed_factor(int d, const float* Wpe, const float* bpe, std::vector<double>& Wc, std::vector<double>& R);
+int ae_encode_tables(int d, int I, int M, int heads, bool mixq, const float* Wpe, const float* bpe, const float* d_lat, const float* mng,
+                     const float* mnb, const float* mWq, const float* mWkv, const float* mWo, const float* mbo, const float* lat,
+                     const float* Wqp, const float* bqp, const float* cg, const float* cb, const float* cWq, const float* cWkv,
+                     const float* cWo, const float* cbo, std::vector<float>& Rf, std::vector<float>& Q1, std::vector<float>& T4,
+                     std::vector<float>& X0, std::vector<float>& T1, std::vector<float>& T3, std::vector<float>& c3);
+int ae_enc_features(const float* pc, const float* basis, const float* Rf, void* F, void* G, int B, int P, int Pp, hipStream_t st);
+int ae_enc_qproj(const float* xin, const float* X0, float* x, const float* gamma, const float* beta, const float* T1, float* Qo, int rows, int M,
+                 int d, hipStream_t st);
 // ---------------------------------------------------------------- ae_decode.hip (streaming query decoder)
 // per-sample decoder context: [ fp16 image M x 128 B | u: M floats | inv_scale + 3 pad floats ]
 inline int64_t ae_ctx_stride(int M) { return (int64_t)M * 128 + (int64_t)M * 4 + 16; }

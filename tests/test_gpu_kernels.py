@@ -206,6 +206,47 @@ def test_attention_row_major_v_transposed_lds_read(H):
     assert torch.equal(out, old)                                   # same arithmetic, different operand path
 
 
+@pytest.mark.parametrize("B,nq,nk,heads,shared", [(1, 512, 10000, 8, True), (2, 128, 1000, 1, False), (3, 64, 130, 2, False)])
+def test_attention_fp16_shared_key_value_rows(H, B, nq, nk, heads, shared):
+    """The folded encoder's attention (ae_encode.hip): fp32 pre-scaled queries, ONE fp16 row per key serving as key and value of every head,
+    ragged key count with a zero pad - against torch in fp32, unsplit and with the keys split over workgroups."""
+    g = torch.Generator("cpu").manual_seed(17)
+    nkp = (nk + 63) // 64 * 64
+    kv = torch.zeros(B, nkp, 64)
+    kv[:, :nk, :52] = torch.rand(B, nk, 52, generator=g) * 2 - 1
+    kv = kv.cuda().half()
+    q = (torch.randn(*((nq,) if shared else (B, nq)), heads * 64, generator=g) * 1.5).cuda()
+    qb = q[None].expand(B, -1, -1) if shared else q
+    kf = kv[:, :nk].float()
+    s = torch.einsum("bqhd,bkd->bhqk", qb.half().float().view(B, nq, heads, 64), kf) * math.log(2.0)
+    ref = torch.einsum("bhqk,bkd->bqhd", torch.softmax(s, dim=-1), kf).reshape(B, nq, heads * 64)
+    for ks in (0, 4, -1):
+        out = H.op_attention_f16kv(q, kv, nk, heads, ks, shared_q=shared)
+        assert rel_l2(out, ref) < 5e-3, ks                            # O is rounded to bf16, P to fp16
+
+
+def test_ae_encoder_point_features_and_inverse_std(H):
+    """Per point: the 52 Fourier features (hardware sin on revolutions) and 1/std of the point's embedding from the 52x52 factor,
+    as the two fp16 rows F and G = rstd.F - against numpy in float64; the pad rows must be zero."""
+    import numpy as np
+    from rald_amd import synth, weights
+    sd = weights.make_state_dict(weights.ae_spec(), seed=0)
+    pc = synth.point_cloud(2, 1000, seed=6)
+    W = np.concatenate([sd["point_embed.mlp.weight"].double().numpy(), sd["point_embed.mlp.bias"].double().numpy()[:, None]], axis=1)
+    Wc = W - W.mean(0, keepdims=True)
+    R = np.linalg.cholesky(Wc.T @ Wc / 512 + 1e-18 * np.eye(52)).T
+    F, G = H.op_ae_enc_features(pc.cuda(), sd["point_embed.basis"].cuda(), torch.from_numpy(R).float().cuda())
+    pts = pc.double().numpy()
+    proj = pts @ sd["point_embed.basis"].double().numpy()
+    f = np.concatenate([np.sin(proj), np.cos(proj), pts, np.ones(pts.shape[:2] + (1,))], axis=2)
+    rstd = 1.0 / np.sqrt(((f @ Wc.T) ** 2).mean(-1) + 1e-5)
+    Fr = f.copy(); Fr[..., 51] = 0
+    assert F.shape == (2, 1024, 64) and float(F[:, 1000:].abs().max()) == 0 and float(G[:, 1000:].abs().max()) == 0
+    assert float(F[:, :, 52:].abs().max()) == 0 and float(G[:, :, 52:].abs().max()) == 0
+    assert np.abs(F[:, :1000, :52].double().cpu().numpy() - Fr).max() < 6e-4          # fp16 rounding of values in [-1, 1] + v_sin
+    assert rel_l2(G[:, :1000, :52].double().cpu(), torch.from_numpy(f * rstd[..., None])) < 5e-4
+
+
 @pytest.mark.parametrize("M,K", [(512, 512), (1000, 2048), (32768, 512), (32768, 2048), (640, 256), (300, 576), (25000, 64), (24704, 576)])
 def test_gemm_residual_with_fused_layernorm(H, M, K):
     """x += A.W^T + bias and the next (Ada)LayerNorm in one kernel: both outputs against fp32 torch,
