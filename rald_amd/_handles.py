@@ -245,7 +245,7 @@ def op_attention_split(Q: torch.Tensor, K: torch.Tensor, Vt: torch.Tensor, nk: i
     """op_attention with the keys split over `ksplit` workgroups per query block (+ combine pass)."""
     Bn, nq, HD = Q.shape
     O = torch.empty(Bn, nq, HD, device=Q.device, dtype=torch.bfloat16)
-    scratch = torch.empty(max(8, lib().rald_op_attention_split_scratch_bytes(max(ksplit, 16), nq, heads, Bn)), device=Q.device, dtype=torch.uint8)
+    scratch = torch.empty(max(8, lib().rald_op_attention_split_scratch_bytes(max(ksplit, 32), nq, heads, Bn)), device=Q.device, dtype=torch.uint8)
     check(lib().rald_op_attention_split(C.c_void_p(_ptr(Q)), Q.stride(1), Q.stride(0), C.c_void_p(_ptr(K)), K.stride(1), K.stride(0),
                                         C.c_void_p(_ptr(Vt)), Vt.stride(1), Vt.stride(0), C.c_void_p(_ptr(O)), O.stride(1), O.stride(0),
                                         nq, nk, K.shape[1], heads, Bn, scale, ksplit, C.c_void_p(_ptr(scratch)), C.c_void_p(_stream())))
@@ -269,7 +269,7 @@ def op_attention_f16kv(Q: torch.Tensor, KV: torch.Tensor, nk: int, heads: int, k
     nq, HD = Q.shape[-2], Q.shape[-1]
     assert Q.dtype == torch.float32 and KV.dtype == torch.float16 and Q.is_contiguous() and KV.is_contiguous() and HD == heads * 64
     O = torch.empty(Bn, nq, HD, device=KV.device, dtype=torch.bfloat16)
-    scratch = torch.empty(lib().rald_op_attention_split_scratch_bytes(max(ksplit, 16), nq, heads, Bn) // 4, device=KV.device, dtype=torch.float32)
+    scratch = torch.empty(lib().rald_op_attention_split_scratch_bytes(max(ksplit, 32), nq, heads, Bn) // 4, device=KV.device, dtype=torch.float32)
     check(lib().rald_op_attention_f16kv(C.c_void_p(_ptr(Q)), HD, 0 if shared_q else nq * HD, C.c_void_p(_ptr(KV)), C.c_void_p(_ptr(O)), HD, nq * HD,
                                         nq, nk, k_rows, heads, Bn, ksplit, C.c_void_p(_ptr(scratch)), C.c_void_p(_stream())))
     return O

@@ -14,6 +14,7 @@
 // all inside ONE streaming kernel (12 B in, 4 B out per query).
 #include "ae.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -298,7 +299,15 @@ int Ae::reserve_encode(int B) {
     e_h = (bf16*)arena.alloc(b * M * d * 2, true);
     e_g = (bf16*)arena.alloc(b * M * 4 * d * 2, true);
     e_ml = (float*)arena.alloc(b * M * 2 * L * 4, true);
-    e_part = (float*)arena.alloc((size_t)attention_split_scratch_bytes(16, (int)M, cfg.heads, B), true);
+    {   // key-split partials of the larger of the two attentions (any batch up to B: the split count falls as the batch grows)
+        int64_t need = 0;
+        for (int bb = 1; bb <= B; ++bb) {
+            const int64_t n1 = cfg.query_type == 0 ? attention_split_scratch_bytes(attention_pick_ksplit((int)M, (int)P, cfg.heads, bb), (int)M, cfg.heads, bb) : 0;
+            const int64_t n2 = attention_split_scratch_bytes(attention_pick_ksplit((int)M, (int)P, 1, bb), (int)M, 1, bb);
+            need = std::max(need, std::max(n1, n2));
+        }
+        e_part = (float*)arena.alloc((size_t)need, true);
+    }
     for (void** p : enc_ptrs()) RALD_CHECK(*p, "ae: encode workspace allocation failed");
     enc_batch = B;
     return 0;

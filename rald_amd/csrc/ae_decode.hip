@@ -159,15 +159,8 @@ __global__ __launch_bounds__(256) void ae_ctx_project_kernel(const float* __rest
         }
     }
     __syncthreads();
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    const float* xr = xs[w];
-    for (int c = 0; c < D; c += 4) {
-        a0 = fmaf(xr[c + 0], t2[(c + 0) * 64 + lane], a0);
-        a1 = fmaf(xr[c + 1], t2[(c + 1) * 64 + lane], a1);
-        a2 = fmaf(xr[c + 2], t2[(c + 2) * 64 + lane], a2);
-        a3 = fmaf(xr[c + 3], t2[(c + 3) * 64 + lane], a3);
-    }
-    const float y = (a0 + a1) + (a2 + a3);
+    __shared__ float red[4][4][64];
+    const float y = project4_rows<D>(xs, t2, red, lane, w);
     if (row < rows) Y[(int64_t)row * 64 + lane] = y;
     // largest |coefficient| of the sample (the fp16 image's scale): max is order-independent, so the atomic keeps the result
     // reproducible; non-negative floats compare like their bit patterns

@@ -213,11 +213,16 @@ int ae_encode_tables(int d, int I, int M, int heads, bool mixq, const float* Wpe
 // ---------------------------------------------------------------------------------------------------------------
 // F [b][Pp][64]: f_0..f_50, 0...          (mix layer: the constant's score is the same for every key, its value is in X0)
 // G [b][Pp][64]: rstd.f_0..f_50, rstd, 0...
-// Rows P..Pp-1 (the attention stages whole 64-key tiles) are zero.  One thread per point; R is read wave-uniformly (scalar loads).
-__global__ __launch_bounds__(256) void ae_enc_features_kernel(const float* __restrict__ pc, const float* __restrict__ basis,
-                                                              const float* __restrict__ Rf, f16* __restrict__ F, f16* __restrict__ G,
-                                                              int P, int Pp, int64_t total) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// Rows P..Pp-1 (the attention stages whole 64-key tiles) are zero.  One thread per point, one wave per workgroup (157 workgroups for
+// 10 000 points); R sits in LDS and is read as broadcast float4s - read wave-uniformly from global memory instead (scalar loads) the 1 378
+// dependent s_load / v_fma pairs took 28 us.
+__global__ __launch_bounds__(64) void ae_enc_features_kernel(const float* __restrict__ pc, const float* __restrict__ basis,
+                                                             const float* __restrict__ Rf, f16* __restrict__ F, f16* __restrict__ G,
+                                                             int P, int Pp, int64_t total) {
+    __shared__ __attribute__((aligned(16))) float sR[FA * FA];
+    for (int i = threadIdx.x; i < FA * FA / 4; i += 64) reinterpret_cast<float4*>(sR)[i] = reinterpret_cast<const float4*>(Rf)[i];
+    __syncthreads();
+    const int64_t idx = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (idx >= total) return;
     const int p = (int)(idx % Pp);
     const int64_t b = idx / Pp;
@@ -248,10 +253,19 @@ __global__ __launch_bounds__(256) void ae_enc_features_kernel(const float* __res
     for (int j = 52; j < 64; ++j) f[j] = 0.f;
     float var = 0.f;
 #pragma unroll
-    for (int i = 0; i < FA; ++i) {
-        float s = 0.f;
+    for (int i = 0; i < FA; ++i) {                       // row i of the upper-triangular factor: columns 4*(i/4) .. 51 (zeros left of the diagonal)
+        constexpr int NCH = FA / 4;
+        float4 r[NCH];                                   // the whole row in flight before its FMAs (the compiler kept 2 reads in flight otherwise)
 #pragma unroll
-        for (int k = i; k < FA; ++k) s = fmaf(Rf[i * FA + k], f[k], s);
+        for (int c = i / 4; c < NCH; ++c) r[c] = *reinterpret_cast<const float4*>(sR + i * FA + 4 * c);
+        asm volatile("" ::: "memory");
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int c = i / 4; c < NCH; ++c) {
+            s0 = fmaf(r[c].x, f[4 * c], s0); s1 = fmaf(r[c].y, f[4 * c + 1], s1);
+            s0 = fmaf(r[c].z, f[4 * c + 2], s0); s1 = fmaf(r[c].w, f[4 * c + 3], s1);
+        }
+        const float s = s0 + s1;
         var = fmaf(s, s, var);
     }
     const float rstd = rsqrtf(var + 1e-5f);
@@ -272,7 +286,7 @@ int ae_enc_features(const float* pc, const float* basis, const float* Rf, void* 
     RALD_CHECK(pc && basis && Rf && F && G && B >= 1 && P >= 1 && Pp >= P && Pp % 64 == 0, "ae_enc_features: bad arguments");
     RALD_CHECK((uintptr_t)F % 16 == 0 && (uintptr_t)G % 16 == 0, "ae_enc_features: 16-byte alignment");
     const int64_t total = (int64_t)B * Pp;
-    hipLaunchKernelGGL(ae_enc_features_kernel, dim3((unsigned)cdiv(total, (int64_t)256)), dim3(256), 0, st, pc, basis, Rf, (f16*)F, (f16*)G, P, Pp, total);
+    hipLaunchKernelGGL(ae_enc_features_kernel, dim3((unsigned)cdiv(total, (int64_t)64)), dim3(64), 0, st, pc, basis, Rf, (f16*)F, (f16*)G, P, Pp, total);
     RALD_HIP(hipGetLastError());
     return 0;
 }
@@ -314,16 +328,9 @@ __global__ __launch_bounds__(256) void ae_enc_qproj_kernel(const float* __restri
         }
     }
     __syncthreads();
-    float a[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = 0.f;
-    const float* xr = xs[w];
-#pragma unroll 2
-    for (int c = 0; c < D; c += 8) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] = fmaf(xr[c + j], T1[(c + j) * 64 + lane], a[j]);
-    }
-    if (row < rows) Qo[(int64_t)row * 64 + lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    __shared__ float red[4][4][64];
+    const float q = project4_rows<D>(xs, T1, red, lane, w);
+    if (row < rows) Qo[(int64_t)row * 64 + lane] = q;
 }
 
 int ae_enc_qproj(const float* xin, const float* X0, float* x, const float* gamma, const float* beta, const float* T1, float* Qo, int rows, int M,

@@ -380,37 +380,48 @@ __global__ __launch_bounds__(256) RALD_ATTN_ATTR void attention_d64_kernel(AttnA
 }
 
 
-// O[b][q][h*64 + d] = sum_s 2^(m_s - M) O_s[d] / sum_s 2^(m_s - M) l_s, M = max_s m_s; one wave per (b, h, q), lane = d
+// O[b][q][h*64 + d] = sum_s 2^(m_s - M) O_s[d] / sum_s 2^(m_s - M) l_s, M = max_s m_s; one wave per (b, h, q), lane = d.
+// Lane s fetches split s's (m, l), so the weights of all <= 64 splits come from one round trip, and the partial rows are then
+// independent loads (the first version walked the splits twice with dependent loads: 8-10 us for 16 splits).
 __global__ __launch_bounds__(256) void attention_combine_kernel(const float* __restrict__ part, int ksplit, int batch, int heads, int nq,
                                                                 bf16* __restrict__ O, int64_t ldo, int64_t strideO) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);        // (b*heads + h)*nq + q
     const int64_t rows = (int64_t)batch * heads * nq;
     if (row >= rows) return;
-    float M = -1e30f;
-    for (int s = 0; s < ksplit; ++s) M = fmaxf(M, part[(s * rows + row) * 66 + 64]);
-    float acc = 0.f, L = 0.f;
-    for (int s = 0; s < ksplit; ++s) {
-        const float* p = part + (s * rows + row) * 66;
-        const float w = fast_exp2(p[64] - M);
-        acc += w * p[lane];
-        L += w * p[65];
+    float ms = -1e30f, ls = 0.f;
+    if (lane < ksplit) {
+        const float2 ml = *reinterpret_cast<const float2*>(part + ((int64_t)lane * rows + row) * 66 + 64);
+        ms = ml.x; ls = ml.y;
     }
+    const float M = wave_max(ms);
+    const float w = lane < ksplit ? fast_exp2(ms - M) : 0.f;
+    const float L = wave_sum(w * ls);
+    float acc0 = 0.f, acc1 = 0.f;
+    int s = 0;
+    for (; s + 4 <= ksplit; s += 4) {
+        const float p0 = part[((int64_t)s * rows + row) * 66 + lane], p1 = part[((int64_t)(s + 1) * rows + row) * 66 + lane];
+        const float p2 = part[((int64_t)(s + 2) * rows + row) * 66 + lane], p3 = part[((int64_t)(s + 3) * rows + row) * 66 + lane];
+        acc0 = fmaf(__shfl(w, s, 64), p0, acc0); acc1 = fmaf(__shfl(w, s + 1, 64), p1, acc1);
+        acc0 = fmaf(__shfl(w, s + 2, 64), p2, acc0); acc1 = fmaf(__shfl(w, s + 3, 64), p3, acc1);
+    }
+    for (; s < ksplit; ++s) acc0 = fmaf(__shfl(w, s, 64), part[((int64_t)s * rows + row) * 66 + lane], acc0);
     const int q = (int)(row % nq);
     const int64_t bh = row / nq;
     const int h = (int)(bh % heads);
     const int64_t b = bh / heads;
-    O[b * strideO + (int64_t)q * ldo + h * 64 + lane] = (bf16)(acc / L);
+    O[b * strideO + (int64_t)q * ldo + h * 64 + lane] = (bf16)((acc0 + acc1) / L);
 }
 
-// few (query block, head, batch) workgroups and many key tiles: split the keys so that ~256 workgroups run
+// few (query block, head, batch) workgroups and many key tiles: split the keys so that ~512 workgroups run (two per CU: a lone workgroup
+// walks its tiles as one dependent chain of ~1.2 us each), at least 4 tiles per workgroup
 int attention_pick_ksplit(int nq, int nk, int heads, int batch) {
     const int64_t wgs = (int64_t)cdiv(nq, 128) * heads * batch;
     const int ntiles = cdiv(nk, 64);
-    if (wgs >= 128 || ntiles < 16) return 1;
-    int ks = (int)(256 / wgs);
+    if (wgs >= 512 || ntiles < 16) return 1;
+    int ks = (int)cdiv((int64_t)512, wgs);
     if (ks > ntiles / 4) ks = ntiles / 4;
-    if (ks > 16) ks = 16;
+    if (ks > 32) ks = 32;
     return ks < 2 ? 1 : ks;
 }
 

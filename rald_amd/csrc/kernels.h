@@ -142,6 +142,32 @@ int add_bcast_cast(const float* a, const float* d, bf16* out, int64_t per_batch,
 int posterior(const float* ml, const float* eps, float* mean_o, float* logvar_o, float* z, float* kl, int B, int rows, int L, hipStream_t st);
 int small_k_linear(const float* in, const float* W, const float* bias, float* out, int M, int K, int N, hipStream_t st);
 
+#ifdef __HIPCC__
+// y[r][lane] = sum_c xs[r][c] * T[c*64 + lane] for the 4 rows a 4-wave workgroup holds (normalised) in LDS: wave w sums the K-quarter
+// [w*D/4, (w+1)*D/4) for ALL 4 rows - each table element is fetched once per workgroup instead of once per row (one wave per row read the
+// whole 128-KiB table per row: 64 MB of L2 traffic for 512 rows) - and the partials meet in LDS.  Returns row w's 64 outputs on wave w.
+template <int D>
+__device__ __forceinline__ float project4_rows(const float (*xs)[D], const float* __restrict__ T, float (*red)[4][64], int lane, int w) {
+    constexpr int KQ = D / 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int c = w * KQ; c < (w + 1) * KQ; c += 32) {
+        float t[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) t[j] = T[(c + j) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = fmaf(xs[r][c + j], t[j], acc[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[w][r][lane] = acc[r];
+    __syncthreads();
+    return (red[0][w][lane] + red[1][w][lane]) + (red[2][w][lane] + red[3][w][lane]);
+}
+#endif
+
 // ---------------------------------------------------------------- ae_encode.hip (folded encoder attentions)
 int ae_embed_factor(int d, const float* Wpe, const float* bpe, std::vector<double>& Wc, std::vector<double>& R);
 int ae_encode_tables(int d, int I, int M, int heads, bool mixq, const float* Wpe, const float* bpe, const float* d_lat, const float* mng,
