@@ -26,16 +26,25 @@ namespace rald {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-template <int BM, int WM, int WN, bool MX>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs a) {
-    constexpr int BN = 512, BK = 64, NSTAGE = 2;
+// BK = 64: LDS rows of 128 bytes, 8 chunks, chunk ^ (row & 7).  BK = 32 (bf16 only): rows of 64 bytes, 4 chunks, chunk ^ ((row >> 2) & 3) -
+// rows r, r+4, r+8, r+12 share a 256-byte bank row, so a ds_read_b128 lane group (16 rows at one logical chunk) touches all 16 slots of it.
+// With 64-row tiles the BK = 32 form needs 72 KiB of LDS: TWO workgroups per CU, so one streams its epilogue (196 KB of stores) while
+// the other runs its k-loop, and a k-step that waits for HBM leaves the MFMAs to the other workgroup.
+template <int BM, int WM, int WN, bool MX, int BK, bool XLOOP = true>
+__device__ __forceinline__ void gemm_resid_ln_body(const GemmLnArgs& a) {
+    constexpr int BN = 512, NSTAGE = 2;
+    static_assert(BK == 64 || (BK == 32 && !MX), "k-step: 64, or 32 for bf16 operands");
     constexpr int WAVES = WM * WN;
     constexpr int MT = BM / (16 * WM);
     constexpr int NT = BN / (16 * WN);
-    constexpr int CA = BM / 8 / WAVES;
-    constexpr int CB = BN / 8 / WAVES;
-    static_assert(CA >= 1 && CB >= 1 && MT >= 1 && NT >= 1, "tile/wave split");
-    constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
+    constexpr int ROWB = MX ? 128 : BK * 2;                      // bytes per LDS row
+    constexpr int CPR = ROWB / 16;                               // 16-byte chunks per row
+    constexpr int RPP = 1024 / ROWB;                             // rows per DMA piece (one wave instruction = 1 KiB)
+    constexpr int PA = BM / RPP, PB = BN / RPP;                  // pieces per stage
+    constexpr int CA = (PA + WAVES - 1) / WAVES;
+    constexpr int CB = PB / WAVES;
+    static_assert(CB >= 1 && PB % WAVES == 0 && MT >= 1 && NT >= 1 && (PA % WAVES == 0 || PA < WAVES), "tile/wave split");
+    constexpr int STAGE_BYTES = (BM + BN) * ROWB;
     constexpr int ROWB_F = NT * 16 * 4, STRIDE_F = ROWB_F + 16;      // fp32 patch row (x_new)
     constexpr int ROWB_H = NT * 16 * 2, STRIDE_H = ROWB_H + 16;      // bf16 patch row (h)
     constexpr int PATCH = 16 * STRIDE_F;
@@ -48,9 +57,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = blockIdx.x * BM;
-    const int lr = lane >> 3;
-    const int lc = (lane & 7) ^ lr;
-    // operand rows are 128 bytes per k-step in both forms: 64 bf16, or 128 e4m3 (MX: e4m3 + e8m0 per 32, see gemm_fp8.hip)
+    const int lr = lane / CPR;                                    // row inside a DMA piece
+    const int lc = CPR == 8 ? ((lane & 7) ^ lr) : ((lane & 3) ^ ((lr >> 2) & 3));     // source chunk that lands in physical chunk lane % CPR
+    // operand rows per k-step: 128 bytes = 64 bf16 or 128 e4m3 (MX: e4m3 + e8m0 per 32, see gemm_fp8.hip); 64 bytes = 32 bf16
     constexpr int ESZ = MX ? 1 : 2;
     const unsigned char* A0 = MX ? a.A8 : reinterpret_cast<const unsigned char*>(a.A);
     const unsigned char* W0 = MX ? a.W8 : reinterpret_cast<const unsigned char*>(a.W);
@@ -58,20 +67,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs 
     const unsigned char* gB[CB];
 #pragma unroll
     for (int p = 0; p < CA; ++p) {
-        int r = m0 + 8 * (wave + WAVES * p) + lr;
+        int r = m0 + RPP * (wave + WAVES * p) + lr;
         r = r < a.M ? r : a.M - 1;
         gA[p] = A0 + ((int64_t)r * a.lda) * ESZ + lc * 16;
     }
 #pragma unroll
-    for (int p = 0; p < CB; ++p) gB[p] = W0 + ((int64_t)(8 * (wave + WAVES * p) + lr) * a.ldw) * ESZ + lc * 16;
+    for (int p = 0; p < CB; ++p) gB[p] = W0 + ((int64_t)(RPP * (wave + WAVES * p) + lr) * a.ldw) * ESZ + lc * 16;
     auto stage = [&](int kt, int buf) {
         unsigned char* base = smem + buf * STAGE_BYTES;
 #pragma unroll
         for (int p = 0; p < CA; ++p)
-            __builtin_amdgcn_global_load_lds((glb_void*)(gA[p] + kt * 128), (lds_void*)(base + (wave + WAVES * p) * 1024), 16, 0, 0);
+            if (PA >= WAVES || wave < PA)                           // fewer A pieces than waves (64 rows x 64-byte rows): the first PA waves stage them
+                __builtin_amdgcn_global_load_lds((glb_void*)(gA[p] + kt * ROWB), (lds_void*)(base + (wave + WAVES * p) * 1024), 16, 0, 0);
 #pragma unroll
         for (int p = 0; p < CB; ++p)
-            __builtin_amdgcn_global_load_lds((glb_void*)(gB[p] + kt * 128), (lds_void*)(base + BM * 128 + (wave + WAVES * p) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(gB[p] + kt * ROWB), (lds_void*)(base + BM * ROWB + (wave + WAVES * p) * 1024), 16, 0, 0);
     };
 
     typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
@@ -82,6 +92,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs 
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nk = MX ? a.K / 128 : a.K / BK;
+    (void)lr;
     const int fr = lane & 15, fq = lane >> 4;
     if constexpr (MX) {
         typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -175,20 +186,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs 
         if constexpr (q >= 1 && q <= 8) x_add(std::integral_constant<int, q - 1>{});
         if constexpr (q <= 7) x_load(QC);
         const bf16x8* sA = reinterpret_cast<const bf16x8*>(smem + (kt & 1) * STAGE_BYTES);
-        const bf16x8* sB = sA + BM * 8;
+        const bf16x8* sB = sA + BM * CPR;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < BK / 32; ++kk) {
             bf16x8 fa[MT], fb[NT];
             const int chunk = kk * 4 + fq;
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int r = wm * (BM / WM) + i * 16 + fr;
-                fa[i] = sA[r * 8 + (chunk ^ (r & 7))];
+                fa[i] = sA[r * CPR + (chunk ^ (CPR == 8 ? (r & 7) : ((r >> 2) & 3)))];
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int r = wn * (BN / WN) + j * 16 + fr;
-                fb[j] = sB[r * 8 + (chunk ^ (r & 7))];
+                fb[j] = sB[r * CPR + (chunk ^ (CPR == 8 ? (r & 7) : ((r >> 2) & 3)))];
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
@@ -198,7 +209,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs 
         }
     };
     stage(0, 0);
-    if (nk >= 9) {                                                    // K >= 576: pieces over the first eight k-steps
+    if constexpr (!XLOOP) {                                           // two workgroups per CU: the other one covers this one's epilogue reads
+        for (int kt = 0; kt < nk; ++kt) kstep(kt, std::integral_constant<int, 9>{});
+    } else if (nk >= 9) {                                             // K >= 576: pieces over the first eight k-steps
         kstep(0, std::integral_constant<int, 0>{}); kstep(1, std::integral_constant<int, 1>{});
         kstep(2, std::integral_constant<int, 2>{}); kstep(3, std::integral_constant<int, 3>{});
         kstep(4, std::integral_constant<int, 4>{}); kstep(5, std::integral_constant<int, 5>{});
@@ -241,7 +254,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs 
             const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
             // (bf16 operands: x_old is already in the accumulators, see the main loop)
             float4 xo = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (MX) {
+            if constexpr (MX || !XLOOP) {
                 const nt_f32x4 xv = nt_io ? __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(a.x + (int64_t)m * BN + n))
                                           : *reinterpret_cast<const nt_f32x4*>(a.x + (int64_t)m * BN + n);
                 xo = make_float4(xv[0], xv[1], xv[2], xv[3]);
@@ -349,6 +362,30 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs 
 }
 
 template <int BM, int WM, int WN, bool MX>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs a) { gemm_resid_ln_body<BM, WM, WN, MX, 64>(a); }
+#ifdef RALD_PROBE
+// MEASURED DEAD END, probe builds only (tools/ab_ln_pair.py): 64-row tiles, 32-deep k-steps, two workgroups per CU (4 waves per SIMD, 128
+// registers) so that one workgroup's epilogue streams while the other runs its k-loop.  Same results (x 1e-7, h 2e-5), but 67 vs 46 us at
+// K = 512 and 140 vs 88 us at K = 2048 (B = 64), NFE 13.87 vs 12.41 ms: a 64-row tile re-reads W once per 64 rows - 1 GB of L2 -> LDS
+// traffic per launch at K = 2048 (7.6 TB/s: the L2 is the bound) - and takes twice the barriers per FLOP.  The 128-row tile stays.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_resid_ln_pair_kernel(GemmLnArgs a) {
+    gemm_resid_ln_body<64, 1, 8, false, 32, false>(a);
+}
+
+static int launch_ln_pair(const GemmLnArgs& a, hipStream_t st) {
+    constexpr int smem = 2 * (64 + 512) * 32 * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        RALD_HIP(hipFuncSetAttribute((const void*)gemm_resid_ln_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_resid_ln_pair_kernel, dim3(cdiv(a.M, 64)), dim3(512), smem, st, a);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+#endif
+
+template <int BM, int WM, int WN, bool MX>
 static int launch_ln(const GemmLnArgs& a, hipStream_t st) {
     constexpr int smem = 2 * (BM + 512) * 64 * 2;
     static bool attr_set = false;
@@ -376,6 +413,9 @@ int gemm_resid_ln(const GemmLnArgs& a0, hipStream_t st) {
                a.gstride % 4 == 0, "gemm_resid_ln: 16-byte alignment");
     RALD_CHECK(!mx || (int64_t)a.M * (a.K / 32) < ((int64_t)1 << 31), "gemm_resid_ln: scale index overflow");
     // 128-row tiles (all 160 KiB of LDS) when they cover the chip, 64-row tiles for smaller M
+#ifdef RALD_PROBE
+    if (!mx && RALD_PROBE_ENV("RALD_LN_PAIR", 0) && cdiv(a.M, 64) >= 384) return launch_ln_pair(a, st);
+#endif
     if (cdiv(a.M, 128) >= 192) return mx ? launch_ln<128, 2, 4, true>(a, st) : launch_ln<128, 2, 4, false>(a, st);
     return mx ? launch_ln<64, 1, 8, true>(a, st) : launch_ln<64, 1, 8, false>(a, st);
 }
