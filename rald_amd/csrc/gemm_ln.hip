@@ -26,6 +26,149 @@ namespace rald {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
+// ---- epilogue shared by the main-loop forms: acc (+ x_old already inside unless XEPI) -> x_new, h ---------------------------------
+template <int BM, int WM, int WN, bool XEPI>
+__device__ __forceinline__ void resid_ln_epilogue(const GemmLnArgs& a, f32x4 (&acc)[BM / (16 * WM)][512 / (16 * WN)], unsigned char* smem, int lds_bytes) {
+    constexpr int BN = 512;
+    constexpr int WAVES = WM * WN;
+    constexpr int MT = BM / (16 * WM);
+    constexpr int NT = BN / (16 * WN);
+    constexpr int ROWB_F = NT * 16 * 4, STRIDE_F = ROWB_F + 16;      // fp32 patch row (x_new)
+    constexpr int ROWB_H = NT * 16 * 2, STRIDE_H = ROWB_H + 16;      // bf16 patch row (h)
+    constexpr int PATCH = 16 * STRIDE_F;
+    constexpr int RED_OFF = WAVES * PATCH;                            // float2 red[BM][WN]
+    (void)lds_bytes; (void)ROWB_H;
+    typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM;
+    const int fr = lane & 15, fq = lane >> 4;
+    const bool nt_io = (a.nt_io & 1) != 0;
+    const bool skip_x = RALD_ABLATED(a.nt_io, 2), skip_h = RALD_ABLATED(a.nt_io, 4);   // probe builds, RALD_NT_STORE bits 1 / 2: timing ablations
+    // ---- 1. v = acc + bias + x_old (accumulator layout), row partial sums -------------------------
+    const int mb = m0 + wm * (BM / WM);
+    const int nb = wn * (BN / WN);
+    float s1[MT], s2[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int m = mb + i * 16 + fr;
+        m = m < a.M ? m : a.M - 1;
+        s1[i] = 0.f; s2[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = nb + j * 16 + 4 * fq;
+            const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+            // (bf16 operands: x_old is already in the accumulators, see the main loop)
+            float4 xo = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (XEPI) {
+                const nt_f32x4 xv = nt_io ? __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(a.x + (int64_t)m * BN + n))
+                                          : *reinterpret_cast<const nt_f32x4*>(a.x + (int64_t)m * BN + n);
+                xo = make_float4(xv[0], xv[1], xv[2], xv[3]);
+            }
+            f32x4 v = acc[i][j];
+            v[0] += b.x + xo.x; v[1] += b.y + xo.y; v[2] += b.z + xo.z; v[3] += b.w + xo.w;
+            acc[i][j] = v;
+            s1[i] += (v[0] + v[1]) + (v[2] + v[3]);
+            s2[i] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+        s1[i] += __shfl_xor(s1[i], 16, 64); s2[i] += __shfl_xor(s2[i], 16, 64);
+        s1[i] += __shfl_xor(s1[i], 32, 64); s2[i] += __shfl_xor(s2[i], 32, 64);
+        asm volatile("" ::: "memory");            // keep only one m-tile's x_old loads in flight (register pressure)
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();                 // staging buffers are dead: reuse them (patches + red)
+    asm volatile("" ::: "memory");
+    float2* red = reinterpret_cast<float2*>(smem + RED_OFF);
+    if (fq == 0) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) red[(wm * (BM / WM) + i * 16 + fr) * WN + wn] = make_float2(s1[i], s2[i]);
+    }
+    __syncthreads();
+    float mean[MT], rstd[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WN; ++w) {
+            const float2 p = red[(wm * (BM / WM) + i * 16 + fr) * WN + w];
+            t1 += p.x; t2 += p.y;
+        }
+        mean[i] = t1 * (1.0f / BN);
+        const float var = fmaxf(t2 * (1.0f / BN) - mean[i] * mean[i], 0.f);
+        rstd[i] = rsqrtf(var + a.eps);
+    }
+
+    // ---- 2. x_new (fp32) and h (bf16) out as whole rows through the wave-private patch -------------
+    unsigned char* patch = smem + wave * PATCH;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        // x_new
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            *reinterpret_cast<float4*>(patch + fr * STRIDE_F + (16 * j + 4 * fq) * 4) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        {
+            constexpr int LPR = ROWB_F / 16, RPI = 64 / LPR;
+#pragma unroll
+            for (int r0 = 0; r0 < 16; r0 += RPI) {
+                const int r = r0 + lane / LPR, pc = lane % LPR;
+                const int m = mb + i * 16 + r;
+                const uint4 v = *reinterpret_cast<const uint4*>(patch + r * STRIDE_F + pc * 16);
+                if (m < a.M && !skip_x) {
+                    typedef unsigned int nt_u32x4 __attribute__((ext_vector_type(4)));
+                    if (nt_io) __builtin_nontemporal_store(nt_u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_u32x4*>(a.x + (int64_t)m * BN + nb + pc * 4));
+                    else *reinterpret_cast<uint4*>(a.x + (int64_t)m * BN + nb + pc * 4) = v;
+                }
+            }
+        }
+        // h = (v - mean) * rstd * (add_one + g) + b ; modulation row of this row's sample
+        int m = mb + i * 16 + fr;
+        m = m < a.M ? m : a.M - 1;
+        const int64_t goff = (int64_t)(m / a.rows_per_group) * a.gstride;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = nb + j * 16 + 4 * fq;
+            const float4 gg = *reinterpret_cast<const float4*>(a.g + goff + n);
+            const float4 bb = *reinterpret_cast<const float4*>(a.b + goff + n);
+            const f32x4 v = acc[i][j];
+            *reinterpret_cast<bf16x4*>(patch + fr * STRIDE_H + (16 * j + 4 * fq) * 2) =
+                pack4((v[0] - mean[i]) * rstd[i] * (a.add_one + gg.x) + bb.x, (v[1] - mean[i]) * rstd[i] * (a.add_one + gg.y) + bb.y,
+                      (v[2] - mean[i]) * rstd[i] * (a.add_one + gg.z) + bb.z, (v[3] - mean[i]) * rstd[i] * (a.add_one + gg.w) + bb.w);
+        }
+        {
+            constexpr int LPR = ROWB_H / 16, RPI = 64 / LPR;
+#pragma unroll
+            for (int r0 = 0; r0 < 16; r0 += RPI) {
+                const int r = r0 + lane / LPR, pc = lane % LPR;
+                const int mm = mb + i * 16 + r;
+                const uint4 v = *reinterpret_cast<const uint4*>(patch + r * STRIDE_H + pc * 16);
+                if (a.h8) {
+                    // MXFP8 output: this lane's 16-byte piece is 8 consecutive columns, 4 consecutive lanes = one 32-column
+                    // block (nb and the pieces are 32-column aligned); every lane of the wave takes part in the shuffles
+                    const bf16x8 hv = *reinterpret_cast<const bf16x8*>(&v);
+                    float f[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = (float)hv[e];
+                    const int64_t mc = mm < a.M ? mm : a.M - 1;
+                    const int col = nb + pc * 8;
+                    unsigned char q8[8] __attribute__((aligned(8)));
+                    unsigned char sc;
+                    mx8_block(f, q8, &sc, true);
+                    if (mm < a.M) {
+                        *reinterpret_cast<uint2*>(a.h8 + mc * BN + col) = *reinterpret_cast<const uint2*>(q8);
+                        if ((pc & 3) == 0) a.hs[mc * (BN / 32) + col / 32] = sc;
+                    }
+                } else if (mm < a.M && !skip_h) {
+                    typedef unsigned int nt_u32x4 __attribute__((ext_vector_type(4)));
+                    if (nt_io) __builtin_nontemporal_store(nt_u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_u32x4*>(a.h + (int64_t)mm * BN + nb + pc * 8));
+                    else *reinterpret_cast<uint4*>(a.h + (int64_t)mm * BN + nb + pc * 8) = v;
+                }
+            }
+        }
+    }
+}
+
 // BK = 64: LDS rows of 128 bytes, 8 chunks, chunk ^ (row & 7).  BK = 32 (bf16 only): rows of 64 bytes, 4 chunks, chunk ^ ((row >> 2) & 3) -
 // rows r, r+4, r+8, r+12 share a 256-byte bank row, so a ds_read_b128 lane group (16 rows at one logical chunk) touches all 16 slots of it.
 // With 64-row tiles the BK = 32 form needs 72 KiB of LDS: TWO workgroups per CU, so one streams its epilogue (196 KB of stores) while
@@ -237,129 +380,149 @@ __device__ __forceinline__ void gemm_resid_ln_body(const GemmLnArgs& a) {
     }
     }
 
-    const bool nt_io = (a.nt_io & 1) != 0;
-    const bool skip_x = RALD_ABLATED(a.nt_io, 2), skip_h = RALD_ABLATED(a.nt_io, 4);   // probe builds, RALD_NT_STORE bits 1 / 2: timing ablations
-    // ---- 1. v = acc + bias + x_old (accumulator layout), row partial sums -------------------------
-    const int mb = m0 + wm * (BM / WM);
-    const int nb = wn * (BN / WN);
-    float s1[MT], s2[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        int m = mb + i * 16 + fr;
-        m = m < a.M ? m : a.M - 1;
-        s1[i] = 0.f; s2[i] = 0.f;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int n = nb + j * 16 + 4 * fq;
-            const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
-            // (bf16 operands: x_old is already in the accumulators, see the main loop)
-            float4 xo = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (MX || !XLOOP) {
-                const nt_f32x4 xv = nt_io ? __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(a.x + (int64_t)m * BN + n))
-                                          : *reinterpret_cast<const nt_f32x4*>(a.x + (int64_t)m * BN + n);
-                xo = make_float4(xv[0], xv[1], xv[2], xv[3]);
-            }
-            f32x4 v = acc[i][j];
-            v[0] += b.x + xo.x; v[1] += b.y + xo.y; v[2] += b.z + xo.z; v[3] += b.w + xo.w;
-            acc[i][j] = v;
-            s1[i] += (v[0] + v[1]) + (v[2] + v[3]);
-            s2[i] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-        }
-        s1[i] += __shfl_xor(s1[i], 16, 64); s2[i] += __shfl_xor(s2[i], 16, 64);
-        s1[i] += __shfl_xor(s1[i], 32, 64); s2[i] += __shfl_xor(s2[i], 32, 64);
-        asm volatile("" ::: "memory");            // keep only one m-tile's x_old loads in flight (register pressure)
-    }
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();                 // staging buffers are dead: reuse them (patches + red)
-    asm volatile("" ::: "memory");
-    float2* red = reinterpret_cast<float2*>(smem + RED_OFF);
-    if (fq == 0) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i) red[(wm * (BM / WM) + i * 16 + fr) * WN + wn] = make_float2(s1[i], s2[i]);
-    }
-    __syncthreads();
-    float mean[MT], rstd[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < WN; ++w) {
-            const float2 p = red[(wm * (BM / WM) + i * 16 + fr) * WN + w];
-            t1 += p.x; t2 += p.y;
-        }
-        mean[i] = t1 * (1.0f / BN);
-        const float var = fmaxf(t2 * (1.0f / BN) - mean[i] * mean[i], 0.f);
-        rstd[i] = rsqrtf(var + a.eps);
-    }
-
-    // ---- 2. x_new (fp32) and h (bf16) out as whole rows through the wave-private patch -------------
-    unsigned char* patch = smem + wave * PATCH;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        // x_new
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-            *reinterpret_cast<float4*>(patch + fr * STRIDE_F + (16 * j + 4 * fq) * 4) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-        {
-            constexpr int LPR = ROWB_F / 16, RPI = 64 / LPR;
-#pragma unroll
-            for (int r0 = 0; r0 < 16; r0 += RPI) {
-                const int r = r0 + lane / LPR, pc = lane % LPR;
-                const int m = mb + i * 16 + r;
-                const uint4 v = *reinterpret_cast<const uint4*>(patch + r * STRIDE_F + pc * 16);
-                if (m < a.M && !skip_x) {
-                    typedef unsigned int nt_u32x4 __attribute__((ext_vector_type(4)));
-                    if (nt_io) __builtin_nontemporal_store(nt_u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_u32x4*>(a.x + (int64_t)m * BN + nb + pc * 4));
-                    else *reinterpret_cast<uint4*>(a.x + (int64_t)m * BN + nb + pc * 4) = v;
-                }
-            }
-        }
-        // h = (v - mean) * rstd * (add_one + g) + b ; modulation row of this row's sample
-        int m = mb + i * 16 + fr;
-        m = m < a.M ? m : a.M - 1;
-        const int64_t goff = (int64_t)(m / a.rows_per_group) * a.gstride;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int n = nb + j * 16 + 4 * fq;
-            const float4 gg = *reinterpret_cast<const float4*>(a.g + goff + n);
-            const float4 bb = *reinterpret_cast<const float4*>(a.b + goff + n);
-            const f32x4 v = acc[i][j];
-            *reinterpret_cast<bf16x4*>(patch + fr * STRIDE_H + (16 * j + 4 * fq) * 2) =
-                pack4((v[0] - mean[i]) * rstd[i] * (a.add_one + gg.x) + bb.x, (v[1] - mean[i]) * rstd[i] * (a.add_one + gg.y) + bb.y,
-                      (v[2] - mean[i]) * rstd[i] * (a.add_one + gg.z) + bb.z, (v[3] - mean[i]) * rstd[i] * (a.add_one + gg.w) + bb.w);
-        }
-        {
-            constexpr int LPR = ROWB_H / 16, RPI = 64 / LPR;
-#pragma unroll
-            for (int r0 = 0; r0 < 16; r0 += RPI) {
-                const int r = r0 + lane / LPR, pc = lane % LPR;
-                const int mm = mb + i * 16 + r;
-                const uint4 v = *reinterpret_cast<const uint4*>(patch + r * STRIDE_H + pc * 16);
-                if (a.h8) {
-                    // MXFP8 output: this lane's 16-byte piece is 8 consecutive columns, 4 consecutive lanes = one 32-column
-                    // block (nb and the pieces are 32-column aligned); every lane of the wave takes part in the shuffles
-                    const bf16x8 hv = *reinterpret_cast<const bf16x8*>(&v);
-                    float f[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] = (float)hv[e];
-                    const int64_t mc = mm < a.M ? mm : a.M - 1;
-                    const int col = nb + pc * 8;
-                    unsigned char q8[8] __attribute__((aligned(8)));
-                    unsigned char sc;
-                    mx8_block(f, q8, &sc, true);
-                    if (mm < a.M) {
-                        *reinterpret_cast<uint2*>(a.h8 + mc * BN + col) = *reinterpret_cast<const uint2*>(q8);
-                        if ((pc & 3) == 0) a.hs[mc * (BN / 32) + col / 32] = sc;
-                    }
-                } else if (mm < a.M && !skip_h) {
-                    typedef unsigned int nt_u32x4 __attribute__((ext_vector_type(4)));
-                    if (nt_io) __builtin_nontemporal_store(nt_u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_u32x4*>(a.h + (int64_t)mm * BN + nb + pc * 8));
-                    else *reinterpret_cast<uint4*>(a.h + (int64_t)mm * BN + nb + pc * 8) = v;
-                }
-            }
-        }
-    }
+    resid_ln_epilogue<BM, WM, WN, (MX || !XLOOP)>(a, acc, smem, NSTAGE * STAGE_BYTES);
 }
+
+#ifdef RALD_PROBE
+// ---- MEASURED DEAD END, probe builds only (tools/ab_ln_ring.py): 128-row form with two operand rings (bf16) ---------------------------
+// Hypothesis: with one 80-KiB stage of A and W in flight (the kernel above) every k-step of a workgroup waits one HBM latency for the A
+// panel (2.4 us per k-step measured for 0.9 us of MFMA work at the datasheet rate).  Result at B = 64: 51 vs 44.5 us (K = 512), 100 vs 88 us
+// (K = 2048), NFE 12.10 vs 11.91 ms, same numbers out (x 1e-7, h 2e-5): with three A stages ahead the k-step takes just as long, so the
+// A latency is not what the loop waits for - it runs at the pace of its LDS traffic (276 KB per k-step and CU) plus the MFMAs at the clock
+// the chip sustains in such loops - and twice the barriers plus the up-front x_old read cost 6-12 us.
+// The two operands have their own rings in the same 160 KiB:
+//   A: 4 stages of 128 rows x 64 k (16 KiB each) - three stages (2.6 us of work) ahead of the MFMAs;
+//   W: 3 stages of 512 rows x 32 k (32 KiB each) - two 32-deep steps ahead (L2 latency);
+// one barrier per 32-deep step, counted vmcnt (the only vector-memory instructions inside the loop are the DMA pieces, issued in a fixed
+// order, so "all but the pieces of the previous step" is a compile-time count).  The residual x_old is loaded STRAIGHT INTO the accumulators
+// before the loop (its latency overlaps the first stages' DMA; no ordinary load sits beside the DMA stream inside the loop, which would make
+// hipcc wait vmcnt(0) there).
+template <int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_ring_kernel(GemmLnArgs a) {
+    constexpr int BM = 128, BN = 512, WAVES = WM * WN;
+    static_assert(WAVES == 8, "8 waves");
+    constexpr int MT = BM / (16 * WM), NT = BN / (16 * WN);
+    constexpr int NA = 4, A_STAGE = BM * 128, NWS = 3, W_STAGE = BN * 64;
+    constexpr int W_OFF = NA * A_STAGE;
+    static_assert(W_OFF + NWS * W_STAGE == 160 * 1024, "the two rings fill the CU's LDS");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM;
+    const int fr = lane & 15, fq = lane >> 4;
+    // DMA sources.  A: pieces of 8 rows x 128 B (2 per wave and stage); W: pieces of 16 rows x 64 B (4 per wave and stage)
+    const unsigned char* gA[2];
+    {
+        const int lr = lane >> 3, lc = (lane & 7) ^ lr;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            int r = m0 + 8 * (wave + WAVES * p) + lr;
+            r = r < a.M ? r : a.M - 1;
+            gA[p] = reinterpret_cast<const unsigned char*>(a.A) + (int64_t)r * a.lda * 2 + lc * 16;
+        }
+    }
+    const unsigned char* gW0;
+    const int64_t w_piece = (int64_t)16 * WAVES * a.ldw * 2;               // bytes between this wave's pieces
+    {
+        const int lr = lane >> 2, lc = (lane & 3) ^ ((lr >> 2) & 3);
+        gW0 = reinterpret_cast<const unsigned char*>(a.W) + (int64_t)(16 * wave + lr) * a.ldw * 2 + lc * 16;
+    }
+    auto stage_a = [&](int ka) {
+        unsigned char* base = smem + (ka & (NA - 1)) * A_STAGE;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            __builtin_amdgcn_global_load_lds((glb_void*)(gA[p] + ka * 128), (lds_void*)(base + (wave + WAVES * p) * 1024), 16, 0, 0);
+    };
+    auto stage_w = [&](int t) {
+        unsigned char* base = smem + W_OFF + (t % NWS) * W_STAGE;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            __builtin_amdgcn_global_load_lds((glb_void*)(gW0 + p * w_piece + t * 64), (lds_void*)(base + (wave + WAVES * p) * 1024), 16, 0, 0);
+    };
+    const int nk64 = a.K / 64, nk32 = a.K / 32;
+    stage_a(0);
+    if (nk64 > 1) stage_a(1);
+    if (nk64 > 2) stage_a(2);
+    stage_w(0);
+    stage_w(1);                                                         // nk32 >= 2
+    // accumulators start as x_old
+    typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 acc[MT][NT];
+    {
+        const int mb = m0 + wm * (BM / WM), nb = wn * (BN / WN);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            int m = mb + i * 16 + fr;
+            m = m < a.M ? m : a.M - 1;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const nt_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(a.x + (int64_t)m * BN + nb + j * 16 + 4 * fq));
+                acc[i][j] = f32x4{v[0], v[1], v[2], v[3]};
+            }
+        }
+    }
+    auto compute = [&](int t) {
+        const unsigned char* sA = smem + ((t >> 1) & (NA - 1)) * A_STAGE;
+        const unsigned char* sW = smem + W_OFF + (t % NWS) * W_STAGE;
+        bf16x8 fa[MT], fb[NT];
+        const int chunk = (t & 1) * 4 + fq;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int r = wm * (BM / WM) + i * 16 + fr;
+            fa[i] = *reinterpret_cast<const bf16x8*>(sA + r * 128 + ((chunk ^ (r & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int r = wn * (BN / WN) + j * 16 + fr;
+            fb[j] = *reinterpret_cast<const bf16x8*>(sW + r * 64 + ((fq ^ ((r >> 2) & 3)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    };
+    auto issue = [&](int t) -> int {                                     // the loads issued during step t; returns their instruction count
+        int n = 0;
+        if (t + 2 < nk32) { stage_w(t + 2); n += 4; }
+        if ((t & 1) == 0 && (t >> 1) + 3 < nk64) { stage_a((t >> 1) + 3); n += 2; }
+        return n;
+    };
+    // step 0: everything issued so far (and x_old) has to be there
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    compute(0);                                                         // (hipcc waits vmcnt(0) for x_old before the first MFMA: nothing may be in flight yet)
+    int pend = issue(0);
+    for (int t = 1; t < nk32; ++t) {
+        // all but the pieces issued during step t-1 have landed: stage t of W (issued at step t-2) and its A stage (earlier still)
+        if (pend == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (pend == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (pend == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                    // ... for every wave; the slots overwritten below were read in step t-1
+        asm volatile("" ::: "memory");
+        pend = issue(t);
+        compute(t);
+    }
+    asm volatile("" ::: "memory");
+    resid_ln_epilogue<BM, WM, WN, false>(a, acc, smem, 160 * 1024);
+}
+
+static int launch_ln_ring(const GemmLnArgs& a, hipStream_t st) {
+    constexpr int smem = 160 * 1024;
+    static bool attr_set = false;
+    auto kern = gemm_resid_ln_ring_kernel<2, 4>;
+    if (!attr_set) {
+        RALD_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(cdiv(a.M, 128)), dim3(512), smem, st, a);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+#endif
 
 template <int BM, int WM, int WN, bool MX>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_kernel(GemmLnArgs a) { gemm_resid_ln_body<BM, WM, WN, MX, 64>(a); }
@@ -415,6 +578,9 @@ int gemm_resid_ln(const GemmLnArgs& a0, hipStream_t st) {
     // 128-row tiles (all 160 KiB of LDS) when they cover the chip, 64-row tiles for smaller M
 #ifdef RALD_PROBE
     if (!mx && RALD_PROBE_ENV("RALD_LN_PAIR", 0) && cdiv(a.M, 64) >= 384) return launch_ln_pair(a, st);
+#endif
+#ifdef RALD_PROBE
+    if (!mx && cdiv(a.M, 128) >= 192 && a.K >= 64 && RALD_PROBE_ENV("RALD_LN_RING", 0)) return launch_ln_ring(a, st);
 #endif
     if (cdiv(a.M, 128) >= 192) return mx ? launch_ln<128, 2, 4, true>(a, st) : launch_ln<128, 2, 4, false>(a, st);
     return mx ? launch_ln<64, 1, 8, true>(a, st) : launch_ln<64, 1, 8, false>(a, st);

@@ -1,5 +1,5 @@
 """A/B of the two-workgroups-per-CU residual+LayerNorm GEMM (64-row tiles, 32-deep k-steps) against the 128-row kernel
-(probe library: RALD_LIB_OVERRIDE=rald_amd/librald_hip_probe.so, switch RALD_LN_PAIR) - stand-alone launches and whole NFEs."""
+(probe library: RALD_LIB_OVERRIDE=rald_amd/librald_hip_probe.so, switch RALD_LN_RING) - stand-alone launches and whole NFEs."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rald_amd import _handles as H, models_radar_generation as G, weights, synth
@@ -26,13 +26,13 @@ for K in (512, 2048):
     for rnd in range(3):
         line = f"K={K} B={B} round {rnd}: "
         for v in ("0", "1"):
-            os.environ["RALD_LN_PAIR"] = v
+            os.environ["RALD_LN_RING"] = v
             x = torch.zeros(M, 512, device="cuda")
             us = timed(lambda: H.op_gemm_resid_ln(A, W, bias, x, gs, bs, gstride=1024, rows_per_group=512, add_one=1.0), 20) * 1e3
             x = torch.ones(M, 512, device="cuda")
             h = H.op_gemm_resid_ln(A, W, bias, x, gs, bs, gstride=1024, rows_per_group=512, add_one=1.0)
             outs[v] = (x.clone(), h.float())
-            line += f"pair={v} {us:6.1f} us ({2.0*M*512*K/us/1e6:5.0f} TF) | "
+            line += f"ring={v} {us:6.1f} us ({2.0*M*512*K/us/1e6:5.0f} TF) | "
         dx = float((outs["0"][0] - outs["1"][0]).norm() / outs["0"][0].norm()); dh = float((outs["0"][1] - outs["1"][1]).norm() / outs["0"][1].norm())
         print(line + f"x diff {dx:.1e} h diff {dh:.1e}", flush=True)
 m = G.LatentArrayTransformer(in_channels=32, t_channels=256, n_heads=8, d_head=64, depth=24)
@@ -42,7 +42,7 @@ x = synth.latents(range(B)).cuda(); cache = h.encode_cond_tokens(synth.cond_toke
 for rnd in range(3):
     line = f"NFE B={B} round {rnd}: "
     for v in ("0", "1"):
-        os.environ["RALD_LN_PAIR"] = v
+        os.environ["RALD_LN_RING"] = v
         ms = timed(lambda: h.denoise(x, cache, 0), 10)
-        line += f"pair={v} {ms:7.3f} ms | "
+        line += f"ring={v} {ms:7.3f} ms | "
     print(line, flush=True)
