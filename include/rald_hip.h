@@ -320,6 +320,14 @@ int rald_op_attn_self_proj(const void* qkv_bf16, int64_t ld, const void* Wo_bf16
 int rald_op_xattn_q2_proj(const void* h_bf16, const void* Wq_bf16, const void* Kc_bf16, int64_t ldk, int64_t strideK, const void* Vt_bf16,
                           int64_t ldvt, int64_t strideVt, const void* Wo_bf16, float* part, int32_t M, int32_t n_latents, int32_t heads,
                           int32_t n_keys, float qscale, void* stream);
+/* The denoiser's first and last layers (LatentArrayTransformer.forward :221, :230-232, fused with the EDM coefficients :424-429; norm.hip),
+ * fp32 throughout.  coef[s][coef_stride] = {c_in, c_skip, c_out, ...} of the sample s = row / rows_per_group.
+ *   proj_in:         x[m][n] = c_in * sum_k xin[m][k] W[n][k]                                   W [D][C]
+ *   final_norm_proj: out[m][c] = c_skip * xin[m][c] + c_out * sum_k LN(x[m]; gamma, beta)[k] Wout[c][k]     Wout [C][D], D = 512 */
+int rald_op_proj_in(const float* xin, const float* W, float* x, int32_t M, int32_t C, int32_t D, const float* coef, int32_t coef_stride,
+                    int32_t rows_per_group, void* stream);
+int rald_op_final_norm_proj(const float* x, const float* gamma, const float* beta, const float* Wout, const float* xin, float* out, int32_t M,
+                            int32_t D, int32_t C, const float* coef, int32_t coef_stride, int32_t rows_per_group, void* stream);
 int rald_op_reduce_resid_ln(const float* part, int32_t slabs, int64_t slab_stride, const float* bias, float* x, void* h_bf16, int32_t M,
                             const float* g, const float* b, int64_t gstride, int32_t rows_per_group, float add_one, float eps, void* stream);
 /* Streaming query decoder (KLAutoEncoder.decode :417-424; rald_amd/csrc/ae_decode.hip).  _tables: the weight-only tables

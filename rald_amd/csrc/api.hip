@@ -455,6 +455,16 @@ int rald_op_ae_encode_tables(int32_t dim, int32_t num_latents, int32_t heads, in
         if (out[i] && !v[i]->empty()) memcpy(out[i], v[i]->data(), v[i]->size() * 4);
     return 0;
 }
+int rald_op_proj_in(const float* xin, const float* W, float* x, int32_t M, int32_t C, int32_t D, const float* coef, int32_t coef_stride,
+                    int32_t rows_per_group, void* stream) {
+    RALD_CHECK(xin && W && x && coef && M >= 1 && rows_per_group >= 1, "rald_op_proj_in: bad argument");
+    return proj_in(xin, W, x, M, C, D, coef, coef_stride, rows_per_group, (hipStream_t)stream);
+}
+int rald_op_final_norm_proj(const float* x, const float* gamma, const float* beta, const float* Wout, const float* xin, float* out, int32_t M,
+                            int32_t D, int32_t C, const float* coef, int32_t coef_stride, int32_t rows_per_group, void* stream) {
+    RALD_CHECK(x && gamma && beta && Wout && xin && out && coef && M >= 1 && rows_per_group >= 1, "rald_op_final_norm_proj: bad argument");
+    return final_norm_proj(x, gamma, beta, Wout, xin, out, M, D, C, coef, coef_stride, rows_per_group, (hipStream_t)stream);
+}
 int rald_op_attn_self_proj(const void* qkv_bf16, int64_t ld, const void* Wo_bf16, float* part, int32_t n_latents, int32_t heads, int32_t batch,
                            void* stream) {
     return attn_self_proj((const bf16*)qkv_bf16, ld, (const bf16*)Wo_bf16, part, n_latents, heads, batch, (hipStream_t)stream);

@@ -206,6 +206,42 @@ def test_attention_row_major_v_transposed_lds_read(H):
     assert torch.equal(out, old)                                   # same arithmetic, different operand path
 
 
+def test_first_and_last_layer_small_and_large_row_forms():
+    """proj_in (:221 + c_in) and final LayerNorm + proj_out + skip/out scaling (:230-232 + :429): both have a small-M and a large-M kernel
+    (weights staged in LDS).  Each against fp64 torch, and the large form bit-equal to the small one on the same rows (same summation order)."""
+    import ctypes as C
+    from rald_amd._lib import lib, check
+    L = lib()
+    g = torch.Generator("cpu").manual_seed(23)
+    M, D, Cc, rpg = 8192 + 40, 512, 32, 512
+    ng = (M + rpg - 1) // rpg
+    xin = torch.randn(M, Cc, generator=g).cuda(); W = (torch.randn(D, Cc, generator=g) / Cc ** 0.5).cuda()
+    coef = (torch.rand(ng, 4, generator=g) + 0.5).cuda()
+    p = lambda t: C.c_void_p(t.data_ptr())
+
+    def run_in(rows):
+        x = torch.empty(rows, D, device="cuda")
+        check(L.rald_op_proj_in(p(xin), p(W), p(x), rows, Cc, D, p(coef), 4, rpg, None))
+        return x
+    x_big, x_small = run_in(M), run_in(4096)
+    cs = coef[:, 0].repeat_interleave(rpg)[:M, None].double()
+    assert rel_l2(x_big.double(), cs * (xin.double() @ W.double().t())) < 1e-6
+    assert torch.equal(x_big[:4096], x_small)
+    x = (torch.randn(M, D, generator=g) * 2 + 0.3).cuda()
+    gam, bet = (1 + 0.1 * torch.randn(D, generator=g)).cuda(), (0.1 * torch.randn(D, generator=g)).cuda()
+    Wo = (torch.randn(Cc, D, generator=g) / D ** 0.5).cuda()
+
+    def run_out(rows):
+        out = torch.empty(rows, Cc, device="cuda")
+        check(L.rald_op_final_norm_proj(p(x), p(gam), p(bet), p(Wo), p(xin), p(out), rows, D, Cc, p(coef), 4, rpg, None))
+        return out
+    o_big, o_small = run_out(M), run_out(4096)
+    xn = torch.nn.functional.layer_norm(x.double(), (D,), gam.double(), bet.double())
+    ref = coef[:, 1].repeat_interleave(rpg)[:M, None].double() * xin.double() + coef[:, 2].repeat_interleave(rpg)[:M, None].double() * (xn @ Wo.double().t())
+    assert rel_l2(o_big.double(), ref) < 2e-6
+    assert torch.equal(o_big[:4096], o_small)
+
+
 @pytest.mark.parametrize("B,nq,nk,heads,shared", [(1, 512, 10000, 8, True), (2, 128, 1000, 1, False), (3, 64, 130, 2, False)])
 def test_attention_fp16_shared_key_value_rows(H, B, nq, nk, heads, shared):
     """The folded encoder's attention (ae_encode.hip): fp32 pre-scaled queries, ONE fp16 row per key serving as key and value of every head,
