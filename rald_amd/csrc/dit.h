@@ -55,6 +55,7 @@ struct Dit {
     Stager stager;
     struct Layer {
         bf16 *w_qk, *w_v, *w_o, *w_q2, *w_o2, *w_ff1, *w_ff2;
+        bf16* w_q2t = nullptr;                                // attn2.to_q transposed [k][h*64+d]: operand of the folded condition keys (cond_fold)
         float *b_o, *b_o2, *b_ff1, *b_ff2;
         // MXFP8 copies of the attention projections (cfg.qkv_dtype == 1): e4m3 elements [rows][D] + e8m0 scales [rows][D/32]
         unsigned char *q8_qk = nullptr, *s8_qk = nullptr, *q8_v = nullptr, *s8_v = nullptr, *q8_q2 = nullptr, *s8_q2 = nullptr;
@@ -106,6 +107,11 @@ struct Dit {
     int reserve(int B);
     int set_sigmas(const float* sig, int n, hipStream_t st);
     int64_t cond_cache_bytes(int B) const;
+    // Folded cross-attention (large batches, bf16): per sample and block the condition's keys absorb to_q and its values absorb to_out,
+    //   Gt[(h,key)][k] = scale.log2e . sum_d K_h[key][d] Wq[h*64+d][k]      Ut[n][(h,key)] = sum_d Wo[n][h*64+d] V_h[key][d]
+    // so the sub-block is  P = softmax_64(h.Gt^T)  (one GEMM with a softmax epilogue)  and  x += P.Ut^T + b  (the residual+LN GEMM with
+    // per-sample weights): two launches instead of three, no attention kernel, no Q / O round trip.
+    bool cond_fold(int B) const;
     int encode_cond_tokens(const float* tokens, int B, void* cache, hipStream_t st);
     int encode_cond(const float* cube, int B, float* out_tokens, void* cache, hipStream_t st);
     int denoise(const float* x, int B, int sigma_row, int per_sample, const void* cache, float* out, int raw_F, hipStream_t st, int slot = 0);

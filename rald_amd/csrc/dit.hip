@@ -118,6 +118,7 @@ int Dit::create() {
         l.w_o = B16((size_t)D * D);
         l.b_o = F32(D);
         l.w_q2 = B16((size_t)D * D);
+        l.w_q2t = B16((size_t)D * D);
         l.w_o2 = B16((size_t)D * D);
         l.b_o2 = F32(D);
         l.w_ff1 = B16((size_t)8 * D * D);
@@ -210,7 +211,15 @@ int Dit::load_weight(const std::string& name, const float* data, int64_t nelem) 
         else if (t == "ff.net.0.proj.bias") { RALD_TRY(need((int64_t)8 * D)); rc = stager.to_f32(data, l.b_ff1, 8 * D, 1, 1, d_geglu_map); }
         else if (t == "ff.net.2.weight") { RALD_TRY(need((int64_t)D * 4 * D)); rc = stager.to_bf16(data, l.w_ff2, D, 4 * D, 4 * D, nullptr); }
         else if (t == "ff.net.2.bias") { RALD_TRY(need(D)); rc = stager.to_f32(data, l.b_ff2, 1, D, D, nullptr); }
-        else if (t == "attn2.to_q.weight") { RALD_TRY(need((int64_t)D * D)); rc = stager.to_bf16(data, l.w_q2, D, D, D, nullptr); }
+        else if (t == "attn2.to_q.weight") {
+            RALD_TRY(need((int64_t)D * D));
+            RALD_TRY(stager.to_bf16(data, l.w_q2, D, D, D, nullptr));
+            std::vector<float> hw((size_t)D * D), ht((size_t)D * D);                  // transposed copy for cond_fold (host: once per load)
+            RALD_HIP(hipMemcpy(hw.data(), data, hw.size() * 4, hipMemcpyDefault));
+            for (int r = 0; r < D; ++r)
+                for (int c2 = 0; c2 < D; ++c2) ht[(size_t)c2 * D + r] = hw[(size_t)r * D + c2];
+            rc = stager.to_bf16(ht.data(), l.w_q2t, D, D, D, nullptr);
+        }
         else if (t == "attn2.to_k.weight") { RALD_TRY(need((int64_t)D * Cd)); rc = stager.to_bf16(data, w_k2_all + (size_t)li * D * Cd, D, Cd, Cd, nullptr); }
         else if (t == "attn2.to_v.weight") { RALD_TRY(need((int64_t)D * Cd)); rc = stager.to_bf16(data, w_v2_all + (size_t)li * D * Cd, D, Cd, Cd, nullptr); }
         else if (t == "attn2.to_out.0.weight") { RALD_TRY(need((int64_t)D * D)); rc = stager.to_bf16(data, l.w_o2, D, D, D, nullptr); }
@@ -353,9 +362,16 @@ int Dit::build_table(SigmaTable& t, const float* sig, int n, hipStream_t st) {
 
 int Dit::set_sigmas(const float* sig, int n, hipStream_t st) { return build_table(tables[0], sig, n, st); }
 
+bool Dit::cond_fold(int B) const {
+    static const bool on = RALD_PROBE_ENV("RALD_COND_FOLD", 1) != 0;
+    return on && cfg.qkv_dtype == 0 && cfg.n_cond_tokens == 64 && cfg.d_head == 64 && cfg.n_heads * 64 == D && cfg.n_latents % 128 == 0 &&
+           !small_m_fused(B * cfg.n_latents, cfg.n_latents, cfg.n_heads, D, cfg.n_cond_tokens);
+}
+
 int64_t Dit::cond_cache_bytes(int B) const {
-    // Kc [B*T][L*D] bf16  +  Vtc [B][L*D][T] bf16
-    return (int64_t)2 * B * cfg.n_cond_tokens * cfg.depth * D * 2;
+    // Kc [B*T][L*D] bf16  +  Vtc [B][L*D][T] bf16;  with cond_fold also Vc [B*T][L*D], Gt [B][L][D][D], Ut [B][L][D][D]
+    const int64_t kv = (int64_t)B * cfg.n_cond_tokens * cfg.depth * D * 2;
+    return cond_fold(B) ? 3 * kv + (int64_t)2 * B * cfg.depth * D * D * 2 : 2 * kv;
 }
 
 int Dit::encode_cond_tokens(const float* tokens, int B, void* cache, hipStream_t st) {
@@ -376,6 +392,28 @@ int Dit::encode_cond_tokens(const float* tokens, int B, void* cache, hipStream_t
     v.strideB = (int64_t)T * Cd;
     v.strideC = (int64_t)L * D * T;
     RALD_TRY(gemm_nt(v, EPI_BF16, st));
+    if (cond_fold(B)) {
+        bf16* Vc = Vtc + (size_t)B * T * L * D;
+        bf16* Gt = Vc + (size_t)B * T * L * D;
+        bf16* Ut = Gt + (size_t)B * L * D * D;
+        GemmArgs vr = gemm_args(ws_tok, Cd, w_v2_all, Cd, Vc, (int64_t)L * D, nullptr, B * T, L * D, Cd);      // V row-major, like K
+        RALD_TRY(gemm_nt(vr, EPI_BF16, st));
+        const float qscale = (1.0f / sqrtf((float)cfg.d_head)) * 1.4426950408889634f;
+        const int H = cfg.n_heads;
+        for (int li = 0; li < L; ++li) {
+            // Gt[b][li][h*64 + key][k] = qscale . sum_d Kc[b][key][li*D + h*64 + d] . Wq^T[k][h*64 + d]
+            GemmArgs gg = gemm_args(Kc + (size_t)li * D, (int64_t)L * D, layers[li].w_q2t, D, Gt + (size_t)li * D * D, D, nullptr, T, D, 64);
+            gg.batch = B; gg.strideA = (int64_t)T * L * D; gg.strideB = 0; gg.strideC = (int64_t)L * D * D;
+            gg.batch2 = H; gg.strideA2 = 64; gg.strideB2 = 64; gg.strideC2 = (int64_t)T * D;
+            gg.alpha = qscale;
+            RALD_TRY(gemm_nt(gg, EPI_BF16, st));
+            // Ut[b][li][n][h*64 + key] = sum_d Wo[n][h*64 + d] . Vc[b][key][li*D + h*64 + d]
+            GemmArgs gu = gemm_args(layers[li].w_o2, D, Vc + (size_t)li * D, (int64_t)L * D, Ut + (size_t)li * D * D, D, nullptr, D, T, 64);
+            gu.batch = B; gu.strideA = 0; gu.strideB = (int64_t)T * L * D; gu.strideC = (int64_t)L * D * D;
+            gu.batch2 = H; gu.strideA2 = 64; gu.strideB2 = 64; gu.strideC2 = T;
+            RALD_TRY(gemm_nt(gu, EPI_BF16, st));
+        }
+    }
     return 0;
 }
 
@@ -426,6 +464,24 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
         if (mnext) RALD_TRY(layernorm_mod(ws_x, ws_h, M, D, mnext, mnext + D, gstride, NL, 1.0f, 1e-5f, st));
         return 0;
     };
+    // the same with one weight matrix per sample (W + sample * strideW): the folded cross-attention's output projection
+    auto resid_ln_w = [&](const bf16* A, int64_t lda, const bf16* W, int64_t ldw, const float* bias, int K, const float* mnext, int64_t strideW) -> int {
+        if (fuse_ln && mnext && gemm_resid_ln_pays(M, K)) {
+            GemmLnArgs g;
+            g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.x = ws_x; g.h = ws_h;
+            g.g = mnext; g.b = mnext + D; g.gstride = gstride; g.rows_per_group = NL; g.add_one = 1.0f; g.eps = 1e-5f;
+            g.M = M; g.K = K; g.strideW = strideW; g.w_rows = NL;
+            return gemm_resid_ln(g, st);
+        }
+        GemmArgs o = gemm_args(A, lda, W, ldw, ws_x, D, bias, NL, D, K);
+        o.batch = B; o.strideA = (int64_t)NL * lda; o.strideB = strideW; o.strideC = (int64_t)NL * D;
+        RALD_TRY(gemm_nt(o, EPI_RESID, st));
+        if (mnext) RALD_TRY(layernorm_mod(ws_x, ws_h, M, D, mnext, mnext + D, gstride, NL, 1.0f, 1e-5f, st));
+        return 0;
+    };
+    const bool fold = cond_fold(B);
+    const bf16* Gt = Vtc + (size_t)2 * B * T * L * D;               // (behind Vc; only there when fold)
+    const bf16* Ut = Gt + (size_t)B * L * D * D;
     RALD_TRY(proj_in(x, w_in, ws_x, M, C, D, coef, cstride, NL, st));
     if (cfg.qkv_dtype >= 1) {
         // ---- MXFP8 q/k/v projections (BASELINE config #5; qkv_dtype 2 adds the GEGLU projection of the feed-forward).  The AdaLN outputs that feed to_q / to_k / to_v (norm1,
@@ -568,6 +624,13 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
         RALD_TRY(attention_d64(a1, st));
         RALD_TRY(resid_ln(ws_o, D, l.w_o, D, l.b_o, D, m2));                       // + norm2 for the next sub-block
         // ---- x += attn2(norm2(x, t), context)                                      (:167)
+        if (fold) {
+            // folded form (see cond_fold in dit.h): P = softmax over each head's 64 keys of h.Gt^T, then x += P.Ut^T + b_o (+ norm3)
+            GemmArgs p1 = gemm_args(ws_h, D, Gt + (size_t)li * D * D, D, ws_q2, D, nullptr, NL, D, D);
+            p1.batch = B; p1.strideA = (int64_t)NL * D; p1.strideB = (int64_t)L * D * D; p1.strideC = (int64_t)NL * D;
+            RALD_TRY(gemm_nt(p1, EPI_SOFTMAX64, st));
+            RALD_TRY(resid_ln_w(ws_q2, D, Ut + (size_t)li * D * D, D, l.b_o2, D, m3, (int64_t)L * D * D));
+        } else {
         GemmArgs q2 = gemm_args(ws_h, D, l.w_q2, D, ws_q2, D, nullptr, M, D, D);
         q2.alpha = qscale;
         RALD_TRY(gemm_nt(q2, EPI_BF16, st));
@@ -579,6 +642,7 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
         a2.nq = NL; a2.nk = T; a2.k_rows = T; a2.heads = cfg.n_heads; a2.batch = B; a2.scale = scale; a2.q_prescaled = 1;
         RALD_TRY(attention_d64(a2, st));
         RALD_TRY(resid_ln(ws_o, D, l.w_o2, D, l.b_o2, D, m3));                     // + norm3
+        }
         }
         // ---- x += ff(norm3(x, t))                                                   (:168)
         GemmArgs f1 = gemm_args(ws_h, D, l.w_ff1, D, ws_g, 4 * D, l.b_ff1, M, 8 * D, D);

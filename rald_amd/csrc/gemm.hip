@@ -235,9 +235,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_glds_kernel(GemmArgs a) 
         tm = tile / ntn;
         tn = tile % ntn;
     }
+    int bz = blockIdx.z;
+    if (nt < 8 && (gridDim.z & 7) == 0) {
+        // batched problems of a few tiles each (the folded cross-attention: 2 x 2 tiles per sample, per-sample B operand): in launch order
+        // a batch entry's tiles land on different XCDs and each re-reads the entry's operands from HBM.  Deal whole batch entries to the
+        // XCDs instead: launch index g -> XCD g & 7, slot g >> 3 -> entry (slot / nt) * 8 + XCD, tile slot % nt.
+        const int g = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const int slot = g >> 3;
+        bz = (slot / nt) * 8 + (g & 7);
+        const int tl = slot % nt;
+        tm = tl / ntn;
+        tn = tl % ntn;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     int64_t oa, ob, coff;
-    gemm_batch_offsets(a, blockIdx.z, oa, ob, coff);
+    gemm_batch_offsets(a, bz, oa, ob, coff);
     const bf16* A = a.A + oa;
     const bf16* B = a.B + ob;
 
@@ -575,6 +587,9 @@ static int launch_glds(const GemmArgs& a, int epi, hipStream_t st) {
         case EPI_F32:   return launch_glds_epi<BM, BN, WM, WN, NSTAGE, EPI_F32>(a, st);
         case EPI_RESID: return launch_glds_epi<BM, BN, WM, WN, NSTAGE, EPI_RESID>(a, st);
         case EPI_GEGLU: return launch_glds_epi<BM, BN, WM, WN, NSTAGE, EPI_GEGLU>(a, st);
+        case EPI_SOFTMAX64:
+            if constexpr ((BN / WN) % 64 == 0 && BM >= 128) return launch_glds_epi<BM, BN, WM, WN, NSTAGE, EPI_SOFTMAX64>(a, st);
+            else { set_error("gemm: the softmax epilogue needs waves of 64-column groups"); return 1; }
         default: set_error("gemm: bad epilogue"); return 1;
     }
 }
@@ -634,6 +649,12 @@ static int gemm_nt_impl(const GemmArgs& a, int epi, hipStream_t st) {
         RALD_CHECK(a.ldc >= a.N / 2, "gemm: GEGLU ldc < N/2");
     } else {
         RALD_CHECK(a.ldc >= a.N, "gemm: ldc < N");
+    }
+    if (epi == EPI_SOFTMAX64) {
+        // whole tiles only: every wave normalises complete 64-column groups of complete rows
+        RALD_CHECK(a.M % 128 == 0 && a.N % 128 == 0 && !a.bias && !a.out8 && a.alpha_ncols >= a.N, "gemm: the softmax epilogue needs M, N % 128 == 0 and no bias");
+        if (a.M % 256 == 0 && a.N % 256 == 0 && (int64_t)(a.M / 256) * (a.N / 256) * nbatch >= 256) return launch_glds<256, 256, 4, 2, 2>(a, epi, st);
+        return launch_glds<128, 128, 2, 2, 2>(a, epi, st);
     }
     if (a.out8) {
         RALD_CHECK(epi == EPI_GEGLU && a.outs && a.batch * a.batch2 == 1 && a.M % 256 == 0 && a.N % 256 == 0 && (a.N / 2) % 32 == 0 &&

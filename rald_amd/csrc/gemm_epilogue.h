@@ -43,6 +43,32 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[MT][NT], const Ge
                 *reinterpret_cast<bf16x4*>(patch + fr * STRIDE + (16 * p + 4 * fq) * 2) = pack4(o01[0], o01[1], o23[0], o23[1]);
             }
         } else {
+            if constexpr (EPI == EPI_SOFTMAX64) {
+                // row fr's 64 columns of a group = 4 n-tiles x the 4 lanes fr, fr+16, fr+32, fr+48 (4 columns each): 16 values in
+                // the lane, two cross-lane steps for the maximum and two for the sum
+                static_assert(NT % 4 == 0, "softmax groups of 64 columns");
+#pragma unroll
+                for (int g = 0; g < NT / 4; ++g) {
+                    float e[16];
+                    float mx = -3.0e38f;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { e[4 * t + c] = a.alpha * acc[i][4 * g + t][c]; mx = fmaxf(mx, e[4 * t + c]); }
+                    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    float sm = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) { e[q] = __builtin_amdgcn_exp2f(e[q] - mx); sm += e[q]; }
+                    sm += __shfl_xor(sm, 16, 64);
+                    sm += __shfl_xor(sm, 32, 64);
+                    const float inv = 1.0f / sm;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        *reinterpret_cast<bf16x4*>(patch + fr * STRIDE + (16 * (4 * g + t) + 4 * fq) * 2) =
+                            pack4(e[4 * t] * inv, e[4 * t + 1] * inv, e[4 * t + 2] * inv, e[4 * t + 3] * inv);
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int n = nb + j * 16 + 4 * fq;
@@ -53,6 +79,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[MT][NT], const Ge
                 const float o0 = al * v[0] + b.x, o1 = al * v[1] + b.y, o2 = al * v[2] + b.z, o3 = al * v[3] + b.w;
                 if constexpr (F32OUT) *reinterpret_cast<float4*>(patch + fr * STRIDE + (16 * j + 4 * fq) * 4) = make_float4(o0, o1, o2, o3);
                 else *reinterpret_cast<bf16x4*>(patch + fr * STRIDE + (16 * j + 4 * fq) * 2) = pack4(o0, o1, o2, o3);
+            }
             }
         }
         // ---- whole rows back out: lane -> (row lane/LPR, 16-byte piece lane%LPR)

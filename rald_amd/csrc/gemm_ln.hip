@@ -28,7 +28,7 @@ typedef const __attribute__((address_space(1))) void glb_void;
 
 // ---- epilogue shared by the main-loop forms: acc (+ x_old already inside unless XEPI) -> x_new, h ---------------------------------
 template <int BM, int WM, int WN, bool XEPI>
-__device__ __forceinline__ void resid_ln_epilogue(const GemmLnArgs& a, f32x4 (&acc)[BM / (16 * WM)][512 / (16 * WN)], unsigned char* smem, int lds_bytes) {
+__device__ __forceinline__ void resid_ln_epilogue(const GemmLnArgs& a, f32x4 (&acc)[BM / (16 * WM)][512 / (16 * WN)], unsigned char* smem, int lds_bytes, int m0) {
     constexpr int BN = 512;
     constexpr int WAVES = WM * WN;
     constexpr int MT = BM / (16 * WM);
@@ -43,7 +43,6 @@ __device__ __forceinline__ void resid_ln_epilogue(const GemmLnArgs& a, f32x4 (&a
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.x * BM;
     const int fr = lane & 15, fq = lane >> 4;
     const bool nt_io = (a.nt_io & 1) != 0;
     const bool skip_x = RALD_ABLATED(a.nt_io, 2), skip_h = RALD_ABLATED(a.nt_io, 4);   // probe builds, RALD_NT_STORE bits 1 / 2: timing ablations
@@ -199,13 +198,22 @@ __device__ __forceinline__ void gemm_resid_ln_body(const GemmLnArgs& a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.x * BM;
+    int mtile = blockIdx.x;
+    if (a.strideW != 0) {
+        // per-group weights: keep a group's tiles on one XCD (launch index g -> XCD g & 7), so its weights cross the fabric once
+        const int tg = a.w_rows / BM, ngroups = (int)gridDim.x / (tg > 0 ? tg : 1);
+        if (tg >= 1 && tg < 8 && ngroups * tg == (int)gridDim.x && (ngroups & 7) == 0) {
+            const int slot = (int)blockIdx.x >> 3;
+            mtile = ((slot / tg) * 8 + ((int)blockIdx.x & 7)) * tg + slot % tg;
+        }
+    }
+    const int m0 = mtile * BM;
     const int lr = lane / CPR;                                    // row inside a DMA piece
     const int lc = CPR == 8 ? ((lane & 7) ^ lr) : ((lane & 3) ^ ((lr >> 2) & 3));     // source chunk that lands in physical chunk lane % CPR
     // operand rows per k-step: 128 bytes = 64 bf16 or 128 e4m3 (MX: e4m3 + e8m0 per 32, see gemm_fp8.hip); 64 bytes = 32 bf16
     constexpr int ESZ = MX ? 1 : 2;
     const unsigned char* A0 = MX ? a.A8 : reinterpret_cast<const unsigned char*>(a.A);
-    const unsigned char* W0 = MX ? a.W8 : reinterpret_cast<const unsigned char*>(a.W);
+    const unsigned char* W0 = MX ? a.W8 : reinterpret_cast<const unsigned char*>(a.W + (int64_t)(m0 / a.w_rows) * a.strideW);
     const unsigned char* gA[CA];
     const unsigned char* gB[CB];
 #pragma unroll
@@ -380,7 +388,7 @@ __device__ __forceinline__ void gemm_resid_ln_body(const GemmLnArgs& a) {
     }
     }
 
-    resid_ln_epilogue<BM, WM, WN, (MX || !XLOOP)>(a, acc, smem, NSTAGE * STAGE_BYTES);
+    resid_ln_epilogue<BM, WM, WN, (MX || !XLOOP)>(a, acc, smem, NSTAGE * STAGE_BYTES, m0);
 }
 
 #ifdef RALD_PROBE
@@ -507,7 +515,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_resid_ln_ring_kernel(GemmLn
         compute(t);
     }
     asm volatile("" ::: "memory");
-    resid_ln_epilogue<BM, WM, WN, false>(a, acc, smem, 160 * 1024);
+    resid_ln_epilogue<BM, WM, WN, false>(a, acc, smem, 160 * 1024, m0);
 }
 
 static int launch_ln_ring(const GemmLnArgs& a, hipStream_t st) {
@@ -575,6 +583,7 @@ int gemm_resid_ln(const GemmLnArgs& a0, hipStream_t st) {
                ((uintptr_t)a.x % 16 == 0) && ((uintptr_t)a.h % 16 == 0) && ((uintptr_t)a.g % 16 == 0) && ((uintptr_t)a.b % 16 == 0) &&
                a.gstride % 4 == 0, "gemm_resid_ln: 16-byte alignment");
     RALD_CHECK(!mx || (int64_t)a.M * (a.K / 32) < ((int64_t)1 << 31), "gemm_resid_ln: scale index overflow");
+    RALD_CHECK(a.strideW == 0 || (!mx && a.w_rows % 128 == 0 && a.strideW % 8 == 0), "gemm_resid_ln: per-group weights need bf16 operands and groups of whole 128-row tiles");
     // 128-row tiles (all 160 KiB of LDS) when they cover the chip, 64-row tiles for smaller M
 #ifdef RALD_PROBE
     if (!mx && RALD_PROBE_ENV("RALD_LN_PAIR", 0) && cdiv(a.M, 64) >= 384) return launch_ln_pair(a, st);

@@ -8,7 +8,8 @@
 namespace rald {
 
 // ---------------------------------------------------------------- gemm.hip
-enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_RESID = 2, EPI_GEGLU = 3 };
+enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_RESID = 2, EPI_GEGLU = 3,
+       EPI_SOFTMAX64 = 4 };   // C_bf16 = softmax over every aligned group of 64 output columns of alpha*acc, in exp2 units (folded cross-attention, dit.hip)
 struct GemmArgs {
     const bf16* A; int64_t lda; int64_t strideA;   // [batch][M][K] activations (K contiguous)
     const bf16* B; int64_t ldb; int64_t strideB;   // [batch][N][K] weights     (K contiguous)
@@ -57,6 +58,8 @@ struct GemmLnArgs {
     const unsigned char *A8 = nullptr, *SA = nullptr, *W8 = nullptr, *SW = nullptr;
     const float* g; const float* b; int64_t gstride; int rows_per_group; float add_one, eps;
     int M, K;
+    // optional per-group weights (bf16 operands): rows [i*w_rows, (i+1)*w_rows) multiply W + i*strideW (w_rows a multiple of 128)
+    int64_t strideW = 0; int w_rows = 1 << 30;
 };
 int gemm_resid_ln(const GemmLnArgs& a, hipStream_t st);
 // true when the fused kernel beats GEMM + separate LayerNorm (measured on MI355X, tools/bench_resid_ln.py and
