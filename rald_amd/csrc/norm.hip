@@ -67,6 +67,9 @@ int layernorm_mod(const float* x, bf16* out, int M, int D, const float* g, const
 // At M <= 2048 rows a [M,512] x K = 2048 product has only a few dozen 64x64 tiles, each walking the whole K; splitting K over
 // the batch dimension fills the chip, and this kernel is the (deterministic) reduction, fused with the residual add and the
 // following LayerNorm - one launch instead of LayerNorm's own.  D = 512, one wave per row.
+// SC: the slab count when it is 4 or 8 (compile time: all 2*SC slab loads of a row are in flight together; with the runtime trip count the
+// loop waited for each slab in turn - 8 dependent L2 round trips, 5 us per launch at 512 rows), 0 = any count.
+template <int SC>
 __global__ __launch_bounds__(256) void reduce_resid_ln_kernel(const float* __restrict__ part, int S, int64_t part_stride, const float* __restrict__ bias,
                                                               float* __restrict__ x, bf16* __restrict__ h, int M, const float* __restrict__ g,
                                                               const float* __restrict__ b, int64_t gstride, int rows_per_group, float add_one, float eps) {
@@ -81,10 +84,23 @@ __global__ __launch_bounds__(256) void reduce_resid_ln_kernel(const float* __res
         v[0] = a0.x + b0.x; v[1] = a0.y + b0.y; v[2] = a0.z + b0.z; v[3] = a0.w + b0.w;
         v[4] = a1.x + b1.x; v[5] = a1.y + b1.y; v[6] = a1.z + b1.z; v[7] = a1.w + b1.w;
     }
+    if constexpr (SC > 0) {
+        float4 p0[SC], p1[SC];
+#pragma unroll
+        for (int s = 0; s < SC; ++s) {
+            const float* p = part + s * part_stride + (int64_t)row * D + lane * 8;
+            p0[s] = *reinterpret_cast<const float4*>(p); p1[s] = *reinterpret_cast<const float4*>(p + 4);
+        }
+#pragma unroll
+        for (int s = 0; s < SC; ++s) {                                  // same order of additions as the loop below
+            v[0] += p0[s].x; v[1] += p0[s].y; v[2] += p0[s].z; v[3] += p0[s].w; v[4] += p1[s].x; v[5] += p1[s].y; v[6] += p1[s].z; v[7] += p1[s].w;
+        }
+    } else {
     for (int s = 0; s < S; ++s) {
         const float* p = part + s * part_stride + (int64_t)row * D + lane * 8;
         const float4 p0 = *reinterpret_cast<const float4*>(p), p1 = *reinterpret_cast<const float4*>(p + 4);
         v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w; v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
+    }
     }
     *reinterpret_cast<float4*>(x + (int64_t)row * D + lane * 8) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4*>(x + (int64_t)row * D + lane * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -111,8 +127,9 @@ int reduce_resid_ln(const float* part, int S, int64_t part_stride, const float* 
                     int64_t gstride, int rows_per_group, float add_one, float eps, hipStream_t st) {
     RALD_CHECK(part && bias && x && S >= 1 && S <= 64 && M >= 1, "reduce_resid_ln: bad arguments");
     RALD_CHECK(!h || (g && b && rows_per_group > 0), "reduce_resid_ln: LayerNorm parameters missing");
-    hipLaunchKernelGGL(reduce_resid_ln_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, part, S, part_stride, bias, x, h, M, g, b, gstride, rows_per_group,
-                       add_one, eps);
+    if (S == 8) hipLaunchKernelGGL(reduce_resid_ln_kernel<8>, dim3(cdiv(M, 4)), dim3(256), 0, st, part, S, part_stride, bias, x, h, M, g, b, gstride, rows_per_group, add_one, eps);
+    else if (S == 4) hipLaunchKernelGGL(reduce_resid_ln_kernel<4>, dim3(cdiv(M, 4)), dim3(256), 0, st, part, S, part_stride, bias, x, h, M, g, b, gstride, rows_per_group, add_one, eps);
+    else hipLaunchKernelGGL(reduce_resid_ln_kernel<0>, dim3(cdiv(M, 4)), dim3(256), 0, st, part, S, part_stride, bias, x, h, M, g, b, gstride, rows_per_group, add_one, eps);
     RALD_HIP(hipGetLastError());
     return 0;
 }
@@ -125,10 +142,7 @@ int resid_splitk_ln(const bf16* A, int64_t lda, const bf16* W, int64_t ldw, cons
     GemmArgs p = gemm_args(A, lda, W, ldw, scratch, 512, nullptr, M, 512, K / splits);
     p.batch = splits; p.strideA = K / splits; p.strideB = K / splits; p.strideC = (int64_t)M * 512;
     RALD_TRY(gemm_nt(p, EPI_F32, st));
-    hipLaunchKernelGGL(reduce_resid_ln_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, scratch, splits, (int64_t)M * 512, bias, x, h, M, g, b, gstride,
-                       rows_per_group, add_one, eps);
-    RALD_HIP(hipGetLastError());
-    return 0;
+    return reduce_resid_ln(scratch, splits, (int64_t)M * 512, bias, x, h, M, g, b, gstride, rows_per_group, add_one, eps, st);
 }
 
 // ---- proj_in: K = C (latent channels, <= 64) is far too small for MFMA and stays fp32.
