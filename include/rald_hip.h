@@ -250,6 +250,16 @@ int rald_op_gemm_nt2(const void* A, int64_t lda, int64_t strideA, int64_t stride
 /* Backward building blocks of the transformer block (what autograd derives for
  * models_radar_generation.py:35-169).  dX = dY.W and dW = dY^T.X run on rald_op_gemm_nt with transposed operands. */
 /* in [batch][batch2][rows][cols] (f32 or bf16) -> out [batch][batch2][cols][rows] bf16 */
+/* Weight gradient of a Linear without transposed copies (rald_amd/csrc/gemm_tn.hip): C[n1][n2] += sum_m A[m][n1] B[m][n2] for row-major bf16
+ * A [M, N1] (= dY) and B [M, N2] (= X), fp32 C accumulated into with atomics; colsum (nullable) [N1] += column sums of A (the bias gradient).
+ * N1, N2, lda, ldb multiples of 8. */
+int rald_op_gemm_tn(const void* A_bf16, int64_t lda, const void* B_bf16, int64_t ldb, float* C, int64_t ldc, float* colsum, int32_t M, int32_t N1,
+                    int32_t N2, void* stream);
+/* Weight gradient of a 3x3x3 Conv3d (Encoder :216-241 under autograd) with the patch matrix never formed: dW [Cout][Cin][27] +=
+ * sum over output voxels of dy[v][co] x[v*stride - pad + offset(tap)][ci] (zero outside the volume); dbias (nullable) += column sums
+ * of dy.  dy [B*OD*OH*OW][Cout] bf16, x [B][ID][IH][IW][Cin] bf16 channels-last, OD = ID / stride ... */
+int rald_op_conv3d_wgrad(const void* dy_bf16, const void* x_bf16, float* dW, float* dbias, int32_t B, int32_t ID, int32_t IH, int32_t IW, int32_t Cin,
+                         int32_t Cout, int32_t stride, int32_t pad, void* stream);
 int rald_op_transpose(const void* in, int32_t in_is_bf16, int64_t ld_in, int64_t stride_in, int64_t stride_in2, void* out_bf16, int64_t ld_out,
                       int64_t stride_out, int64_t stride_out2, int32_t rows, int32_t cols, int32_t batch, int32_t batch2, void* stream);
 /* AdaLayerNorm :119-131 (add_one = 1) / LayerNorm (add_one = 0, scale = weight) backward, D = 512:

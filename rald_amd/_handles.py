@@ -211,6 +211,17 @@ def op_gemm_nt(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = 
     return out
 
 
+def op_gemm_tn(A: torch.Tensor, B: torch.Tensor, C_inout: torch.Tensor, colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C_inout [N1,N2] f32 += A^T.B for row-major bf16 A [M,N1], B [M,N2] (column slices allowed); colsum [N1] f32 += column sums of A."""
+    M, N1 = A.shape
+    N2 = B.shape[1]
+    assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and C_inout.dtype == torch.float32 and B.shape[0] == M
+    assert A.stride(1) == 1 and B.stride(1) == 1 and C_inout.stride(1) == 1 and C_inout.shape == (N1, N2)
+    check(lib().rald_op_gemm_tn(C.c_void_p(_ptr(A)), A.stride(0), C.c_void_p(_ptr(B)), B.stride(0), C.c_void_p(_ptr(C_inout)), C_inout.stride(0),
+                                C.c_void_p(_ptr(colsum) if colsum is not None else 0), M, N1, N2, C.c_void_p(_stream())))
+    return C_inout
+
+
 def op_gemm_resid_ln(A: torch.Tensor, W: torch.Tensor, bias: torch.Tensor, x: torch.Tensor, g: torch.Tensor, b: torch.Tensor,
                      gstride: int = 0, rows_per_group: int = 1 << 30, add_one: float = 0.0, eps: float = 1e-5) -> torch.Tensor:
     """x [M,512] f32 += A [M,K] bf16 @ W [512,K]^T + bias (in place); returns h = LN(x)*(add_one+g)+b as bf16."""

@@ -267,6 +267,14 @@ int rald_op_gemm_nt2(const void* A, int64_t lda, int64_t strideA, int64_t stride
     g.batch2 = batch2; g.strideA2 = strideA2; g.strideB2 = strideB2; g.strideC2 = strideC2;
     return gemm_nt(g, epilogue, (hipStream_t)stream);
 }
+int rald_op_gemm_tn(const void* A_bf16, int64_t lda, const void* B_bf16, int64_t ldb, float* C, int64_t ldc, float* colsum, int32_t M, int32_t N1,
+                    int32_t N2, void* stream) {
+    return gemm_tn((const bf16*)A_bf16, lda, (const bf16*)B_bf16, ldb, C, ldc, colsum, M, N1, N2, (hipStream_t)stream);
+}
+int rald_op_conv3d_wgrad(const void* dy_bf16, const void* x_bf16, float* dW, float* dbias, int32_t B, int32_t ID, int32_t IH, int32_t IW, int32_t Cin,
+                         int32_t Cout, int32_t stride, int32_t pad, void* stream) {
+    return conv3d_wgrad_tn((const bf16*)dy_bf16, (const bf16*)x_bf16, dW, dbias, B, ID, IH, IW, Cin, Cout, stride, pad, (hipStream_t)stream);
+}
 int rald_op_transpose(const void* in, int32_t in_is_bf16, int64_t ld_in, int64_t stride_in, int64_t stride_in2, void* out_bf16, int64_t ld_out,
                       int64_t stride_out, int64_t stride_out2, int32_t rows, int32_t cols, int32_t batch, int32_t batch2, void* stream) {
     TransposeArgs a;

@@ -1,0 +1,227 @@
+// Weight-gradient GEMM: C[n1][n2] += sum_m A[m][n1] . B[m][n2]  - both operands row-major with the CONTRACTED index on the rows.
+//
+// This is dW = dY^T . X of every Linear in the training step (autograd's mm(dY.t(), X) in the
+// reference, engine_generation.py:93-104): dY [M, N1] and X [M, N2] are activations as the forward / backward pass leaves them,
+// M = batch x 512 rows.  The NT engine (gemm.hip) needs both operands K-contiguous, i.e. two transposed bf16 copies per Linear
+// (~900 transpose launches and 2 x the activation bytes per iteration) and then meets a GEMM with a handful of output tiles and
+// K = M.  Here the tiles are staged as they lie in memory - [64 rows of m][128 columns] by LDS-DMA - and the MFMA fragments are
+// read TRANSPOSED from LDS (ds_read_b64_tr_b16: a 16-lane group reads a 4 x 16 block and every lane receives one column of
+// it), and the m range is split over blockIdx.z so that a 512 x 512 gradient still fills the chip; the splits meet in fp32
+// atomics (the gradient buffers are accumulated into anyway; order-dependent in the last bits like the other atomics of the
+// backward pass).
+//
+// LDS image of a tile: rows of 256 bytes (128 bf16), 16-byte chunk c of row m stored at c ^ f(m), f(m) = 2 (m & 3) | 8 ((m >> 3) & 1):
+// the 4 rows of a transposed block (32 bytes each) land in 4 different 32-byte slots, and the row blocks of lane groups 0 / 1
+// (rows 8 apart) in different halves of the 256-byte bank row.
+#include "common.h"
+#include "kernels.h"
+
+namespace rald {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+struct GemmTnArgs {
+    const bf16* A; int64_t lda;      // [M][N1]
+    const bf16* B; int64_t ldb;      // [M][N2]
+    float* C; int64_t ldc;           // [N1][N2] fp32, accumulated into
+    float* colsum;                   // optional [N1]: += sum_m A[m][n1] (the bias gradient of the same Linear)
+    int M, N1, N2, rows_per_split;
+    // CONV form (weight gradient of a 3x3x3 Conv3d, channels-last input x [B][ID][IH][IW][Cin]): row m = output voxel, column
+    // n2 = tap * Cin + ci of the VIRTUAL patch matrix B[m][n2] = x[b][od*s - p + kd][oh*s - p + kh][ow*s - p + kw][ci] (zero outside);
+    // C is the parameter's own [Cout][Cin][27] layout: output column n2 lands at ci * 27 + tap.
+    int ID, IH, IW, Cin, OD, OH, OW, stride, pad;
+    int lw, lh, ld;                  // log2 of OW, OH, OD when all three are powers of two (the decode is shifts then), else -1
+};
+
+__device__ __attribute__((aligned(16))) bf16 g_tn_zero[8];      // (zero-initialised) source of the patch matrix' padding
+
+__device__ __forceinline__ int tn_swz(int m) { return ((m & 3) << 1) | (((m >> 3) & 1) << 3); }
+
+// A-type fragment (16 columns n0..n0+15 as the MFMA's row index, k = 8 kq .. 8 kq + 7 of the 32-row k-step at tile row m0):
+// lane (i = lane & 15, kq = lane >> 4) receives tile[m0 + 8 kq + e][n0 + i], e = 0..7
+__device__ __forceinline__ bf16x8 tn_frag(const unsigned char* tile, int m0, int n0, int lane) {
+    const int kq = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    const int r0 = m0 + 8 * kq + qq, r1 = r0 + 4;
+    const int c = (n0 >> 3) + (pp >> 1);                       // logical 16-byte chunk holding columns n0 + 4 pp .. + 3
+    const unsigned char* p0 = tile + r0 * 256 + ((c ^ tn_swz(r0)) << 4) + 8 * (pp & 1);
+    const unsigned char* p1 = tile + r1 * 256 + ((c ^ tn_swz(r1)) << 4) + 8 * (pp & 1);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+    return __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// NARROW (N1 <= 64): the n1 half of the 128-wide tile would be idle, so the two wave rows split each 64-row step between them instead
+// (wave row wa takes the 32-row sub-step ks = wa); their partial sums meet in the same atomics as the row splits.
+template <bool CONV, bool NARROW>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
+    constexpr int TILE = 64 * 256;                              // one operand tile: 64 rows of m x 128 columns
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE];      // [stage][A | B]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wa = wave >> 1, wb = wave & 1;                    // wave tile: 64 (n1) x 64 (n2)
+    const int n1_0 = blockIdx.y * 128, n2_0 = blockIdx.x * 128;
+    const int m_begin = blockIdx.z * a.rows_per_split;
+    int m_end = m_begin + a.rows_per_split;
+    if (m_end > a.M) m_end = a.M;
+    const int nsteps = (m_end - m_begin + 63) / 64;
+    if (nsteps <= 0) return;
+    // DMA: one instruction = 4 rows x 256 B; wave w stages rows 4 (w + 4 p) .. + 3 of each operand tile, p = 0..3
+    const int lr = lane >> 4, pc = lane & 15;
+    auto stage = [&](int s, int buf) {
+        unsigned char* base = smem + buf * 2 * TILE;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int piece = wave + 4 * p, r = 4 * piece + lr;
+            const int lc = pc ^ tn_swz(r);
+            int m = m_begin + 64 * s + r;
+            m = m < m_end ? m : m_end - 1;                      // ragged tail: duplicated rows are masked out of the product below
+            int ca = n1_0 + lc * 8, cb = n2_0 + lc * 8;
+            ca = ca + 8 <= a.N1 ? ca : a.N1 - 8;                // columns past the matrix: re-read the last 8 (those outputs are not stored)
+            cb = cb + 8 <= a.N2 ? cb : a.N2 - 8;
+            __builtin_amdgcn_global_load_lds((glb_void*)(a.A + (int64_t)m * a.lda + ca), (lds_void*)(base + piece * 1024), 16, 0, 0);
+            const bf16* srcb;
+            if constexpr (CONV) {
+                const int tap = cb / a.Cin, ci = cb - tap * a.Cin;              // (Cin % 8 == 0: a chunk never straddles two taps)
+                const int kd = tap / 9, kh = (tap - 9 * kd) / 3, kw = tap - 9 * kd - 3 * kh;
+                int ow, oh, od, b;
+                if (a.lw >= 0) {
+                    ow = m & (a.OW - 1);
+                    int r2 = m >> a.lw;
+                    oh = r2 & (a.OH - 1); r2 >>= a.lh;
+                    od = r2 & (a.OD - 1);
+                    b = r2 >> a.ld;
+                } else {
+                    ow = m % a.OW;
+                    int r2 = m / a.OW;
+                    oh = r2 % a.OH; r2 /= a.OH;
+                    od = r2 % a.OD;
+                    b = r2 / a.OD;
+                }
+                const int id = od * a.stride - a.pad + kd, ih = oh * a.stride - a.pad + kh, iw = ow * a.stride - a.pad + kw;
+                const bool in = (unsigned)id < (unsigned)a.ID && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW;
+                srcb = in ? a.B + ((((int64_t)b * a.ID + id) * a.IH + ih) * a.IW + iw) * a.Cin + ci : g_tn_zero;
+            } else srcb = a.B + (int64_t)m * a.ldb + cb;
+            __builtin_amdgcn_global_load_lds((glb_void*)srcb, (lds_void*)(base + TILE + piece * 1024), 16, 0, 0);
+        }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 csum[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) csum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool want_cs = a.colsum != nullptr && blockIdx.x == 0 && wb == 0;
+    const int n1_w = NARROW ? 0 : 64 * wa;                      // first n1 column of this wave inside the tile
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+    stage(0, 0);
+    for (int s = 0; s < nsteps; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + 1 < nsteps) stage(s + 1, (s + 1) & 1);
+        const unsigned char* tA = smem + (s & 1) * 2 * TILE;
+        const unsigned char* tB = tA + TILE;
+        const int valid = m_end - (m_begin + 64 * s);           // rows of this step that exist (>= 64 except on the last step)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (NARROW && ks != wa) continue;
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = tn_frag(tA, 32 * ks, (NARROW ? 0 : 64 * wa) + 16 * i, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = tn_frag(tB, 32 * ks, 64 * wb + 16 * j, lane);
+            if (valid < 64) {                                   // ragged tail (wave-uniform): zero the k positions that are padding
+                const int k0 = 32 * ks + 8 * (lane >> 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (k0 + e >= valid) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) fa[i][e] = (bf16)0.f;
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                if (want_cs) csum[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, csum[i], 0, 0, 0);
+            }
+        }
+    }
+    // acc[i][j][e] = C[n1_0 + 64 wa + 16 i + 4 (lane >> 4) + e][n2_0 + 64 wb + 16 j + (lane & 15)]
+    const int rq = lane >> 4, cl = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n1 = n1_0 + n1_w + 16 * i + 4 * rq + e;
+            if (n1 >= a.N1) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n2 = n2_0 + 64 * wb + 16 * j + cl;
+                if (n2 >= a.N2) continue;
+                if constexpr (CONV) {
+                    const int tap = n2 / a.Cin, ci = n2 - tap * a.Cin;
+                    unsafeAtomicAdd(a.C + (int64_t)n1 * a.ldc + ci * 27 + tap, acc[i][j][e]);
+                } else unsafeAtomicAdd(a.C + (int64_t)n1 * a.ldc + n2, acc[i][j][e]);
+            }
+            if (want_cs && cl == 0) unsafeAtomicAdd(a.colsum + n1, csum[i][e]);
+        }
+}
+
+static int tn_launch(GemmTnArgs a, bool conv, hipStream_t st) {
+    const int t1 = cdiv(a.N1, 128), t2 = cdiv(a.N2, 128);
+    // split the m range until ~1024 workgroups run, but keep at least 256 rows (4 k-steps) per split
+    int splits = cdiv(1024, t1 * t2);
+    const int max_splits = cdiv(a.M, 256);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    const int rows = (int)round_up(cdiv(a.M, splits), 64);
+    splits = cdiv(a.M, rows);
+    RALD_CHECK(splits <= 65535, "gemm_tn: too many splits");
+    a.rows_per_split = rows;
+    const bool narrow = a.N1 <= 64;
+    if (conv && narrow) hipLaunchKernelGGL((gemm_tn_kernel<true, true>), dim3(t2, t1, splits), dim3(256), 0, st, a);
+    else if (conv) hipLaunchKernelGGL((gemm_tn_kernel<true, false>), dim3(t2, t1, splits), dim3(256), 0, st, a);
+    else if (narrow) hipLaunchKernelGGL((gemm_tn_kernel<false, true>), dim3(t2, t1, splits), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_tn_kernel<false, false>), dim3(t2, t1, splits), dim3(256), 0, st, a);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+int gemm_tn(const bf16* A, int64_t lda, const bf16* B, int64_t ldb, float* C, int64_t ldc, float* colsum, int M, int N1, int N2, hipStream_t st) {
+    RALD_CHECK(A && B && C && M >= 1 && N1 >= 8 && N2 >= 8, "gemm_tn: bad arguments");
+    RALD_CHECK(lda % 8 == 0 && ldb % 8 == 0 && lda >= N1 && ldb >= N2 && ldc >= N2, "gemm_tn: leading dimensions (16-byte rows)");
+    RALD_CHECK(N1 % 8 == 0 && N2 % 8 == 0, "gemm_tn: N1, N2 must be multiples of 8");
+    RALD_CHECK((uintptr_t)A % 16 == 0 && (uintptr_t)B % 16 == 0, "gemm_tn: 16-byte alignment");
+    GemmTnArgs a = {};
+    a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.colsum = colsum; a.M = M; a.N1 = N1; a.N2 = N2;
+    return tn_launch(a, false, st);
+}
+
+// dW [Cout][Cin][27] += sum over output voxels of dy[v][co] . x[v + offset(tap)][ci];  dbias [Cout] += column sums of dy.
+// dy [B*OD*OH*OW][Cout] bf16, x [B][ID][IH][IW][Cin] bf16 (channels-last), OD = ID / stride etc. (3x3x3 kernel).
+int conv3d_wgrad_tn(const bf16* dy, const bf16* x, float* dW, float* dbias, int B, int ID, int IH, int IW, int Cin, int Cout, int stride, int pad,
+                    hipStream_t st) {
+    RALD_CHECK(dy && x && dW && B >= 1 && ID >= 1 && IH >= 1 && IW >= 1 && (stride == 1 || stride == 2) && pad >= 0, "conv3d_wgrad_tn: bad arguments");
+    RALD_CHECK(Cin % 8 == 0 && Cout % 8 == 0, "conv3d_wgrad_tn: channel counts must be multiples of 8");
+    RALD_CHECK((uintptr_t)dy % 16 == 0 && (uintptr_t)x % 16 == 0, "conv3d_wgrad_tn: 16-byte alignment");
+    const int OD = ID / stride, OH = IH / stride, OW = IW / stride;
+    const int64_t M = (int64_t)B * OD * OH * OW;
+    RALD_CHECK(M >= 1 && M < ((int64_t)1 << 31) && (int64_t)B * ID * IH * IW * Cin < ((int64_t)1 << 40), "conv3d_wgrad_tn: volume too large");
+    GemmTnArgs a = {};
+    a.A = dy; a.lda = Cout; a.B = x; a.ldb = 0; a.C = dW; a.ldc = (int64_t)Cin * 27; a.colsum = dbias; a.M = (int)M; a.N1 = Cout; a.N2 = 27 * Cin;
+    a.ID = ID; a.IH = IH; a.IW = IW; a.Cin = Cin; a.OD = OD; a.OH = OH; a.OW = OW; a.stride = stride; a.pad = pad;
+    auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+    a.lw = lg(OW); a.lh = lg(OH); a.ld = lg(OD);
+    if (a.lw < 0 || a.lh < 0 || a.ld < 0) a.lw = a.lh = a.ld = -1;
+    return tn_launch(a, true, st);
+}
+
+}  // namespace rald

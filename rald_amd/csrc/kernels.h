@@ -66,6 +66,13 @@ int gemm_resid_ln(const GemmLnArgs& a, hipStream_t st);
 // whole-NFE sweeps: wins from M = 16384 on for K = 512 and K = 2048, +1 % per NFE at B = 32; at M = 8192 it loses)
 inline bool gemm_resid_ln_pays(int M, int K = 512) { (void)K; return M >= 16384; }
 
+// ---------------------------------------------------------------- gemm_tn.hip
+// C[n1][n2] += sum_m A[m][n1] . B[m][n2] (fp32, atomics); colsum (optional) [n1] += sum_m A[m][n1].  Weight / bias gradient of a Linear.
+int gemm_tn(const bf16* A, int64_t lda, const bf16* B, int64_t ldb, float* C, int64_t ldc, float* colsum, int M, int N1, int N2, hipStream_t st);
+// the same with B = the virtual patch matrix of a 3x3x3 Conv3d over channels-last x: dW [Cout][Cin][27] += ..., dbias += column sums of dy
+int conv3d_wgrad_tn(const bf16* dy, const bf16* x, float* dW, float* dbias, int B, int ID, int IH, int IW, int Cin, int Cout, int stride, int pad,
+                    hipStream_t st);
+
 // ---------------------------------------------------------------- norm.hip
 // out_bf16[m][c] = LN(x[m])[c] * (add_one + g[s][c]) + b[s][c],  s = (m / rows_per_group) * gstride
 int layernorm_mod(const float* x, bf16* out, int M, int D, const float* g, const float* b,

@@ -94,34 +94,18 @@ def down_dgrad(dy: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
 
 
 def conv_wgrad(dy: torch.Tensor, x16: torch.Tensor, dW: torch.Tensor, dbias: Optional[torch.Tensor], stride: int = 1, pad: int = 1) -> None:
-    """dW [Cout, Cin, 3, 3, 3] (f32, accumulated) += sum over voxels of dy (x) patches(x16); dbias += column sums of dy."""
+    """dW [Cout, Cin, 3, 3, 3] (f32, accumulated) += sum over voxels of dy (x) patches(x16); dbias += column sums of dy.
+    One launch of the row-contracting GEMM whose second operand is the VIRTUAL patch matrix (csrc/gemm_tn.hip, CONV form): the
+    [voxels x 27 Cin] patches are gathered from the channels-last input by the LDS-DMA itself (padding from a zero line), so no
+    im2col buffer (7 GB written per full-resolution conv at B = 8 before), no transposed dy, no split-K partials to sum."""
     B, ID, IH, IW, Cin = x16.shape
     Cout = dy.shape[-1]
-    M = dy.numel() // Cout
-    dy2 = dy.reshape(M, Cout)
-    dW2 = dW.view(Cout, Cin * 27)
-    nchunk = max(64, min(M, 1 << max(6, ((1 << 27) // (Cin * 27 * 2)).bit_length() - 1)))      # power of two, <= 128 MiB of patches
-    for m0 in range(0, M, nchunk):
-        n = min(nchunk, M - m0)
-        npad = -(-n // 64) * 64                              # the GEMM contracts over the chunk: multiple of 64 (zero rows beyond M)
-        col = torch.empty(Cin * 27, npad, device=dy.device, dtype=torch.bfloat16)
-        check(lib().rald_op_im2col_t(_p(x16), _p(col), B, ID, IH, IW, Cin, stride, pad, m0, npad, _st()))
-        rows = dy2[m0:m0 + n]
-        if npad != n:
-            rows = torch.cat([rows, torch.zeros(npad - n, Cout, device=dy.device, dtype=dy.dtype)], 0)
-        dyT = TO.T2(rows)                                    # [Cout, npad]
-        ks = 1
-        while ks < 16 and npad % (2 * ks * 2048) == 0:       # split the long contraction: Cout x Cin*27 outputs alone are too few tiles
-            ks *= 2
-        if ks == 1:
-            op_gemm_nt(dyT, col, epilogue=2, C_inout=dW2)
-        else:
-            kk = npad // ks
-            part = torch.empty(ks, Cout, Cin * 27, device=dy.device, dtype=torch.float32)
-            TO.gemm2(dyT, npad, kk, 0, col, npad, kk, 0, part, Cin * 27, Cout * Cin * 27, 0, Cout, Cin * 27, kk, ks, 1, epilogue=1)
-            TO.colsum(part.view(ks, Cout * Cin * 27), dW2.view(-1))
-    if dbias is not None:
-        TO.colsum(dy2, dbias)
+    dy16 = dy.reshape(-1, Cout)
+    if dy16.dtype != torch.bfloat16:
+        dy16 = TO.cast_bf16(dy16.contiguous())
+    assert x16.dtype == torch.bfloat16 and x16.is_contiguous() and dW.is_contiguous() and dW.dtype == torch.float32
+    assert dy16.shape[0] == B * (ID // stride) * (IH // stride) * (IW // stride)
+    check(lib().rald_op_conv3d_wgrad(_p(dy16), _p(x16), _p(dW), _p(dbias), B, ID, IH, IW, Cin, Cout, stride, pad, _st()))
 
 
 def _g(p: torch.nn.Parameter) -> torch.Tensor:
@@ -192,8 +176,7 @@ class EncoderTrainer:
             d2 = dout.view(-1, cout)
             W16 = P(".nin_shortcut.weight").data.view(cout, cin).to(torch.bfloat16)
             dx = op_gemm_nt(TO.cast_bf16(d2), TO.T2(W16), epilogue=1).view(*x.shape)
-            op_gemm_nt(TO.T2(d2), TO.T2(TO.cast_bf16(x).view(-1, cin)), epilogue=2, C_inout=_g(P(".nin_shortcut.weight")).view(cout, cin))
-            TO.colsum(d2, _g(P(".nin_shortcut.bias")))
+            TO.lin_wgrad(d2, TO.cast_bf16(x).view(-1, cin), _g(P(".nin_shortcut.weight")).view(cout, cin), _g(P(".nin_shortcut.bias")))
         groupnorm_bwd(x, st1, P(".norm1.weight").data, P(".norm1.bias").data, dh1, dx, _g(P(".norm1.weight")), _g(P(".norm1.bias")), True, True)
         return dx
 
@@ -234,8 +217,7 @@ class EncoderTrainer:
         n16, _ = groupnorm(x, P(".norm.weight").data, P(".norm.bias").data, False)
         n2 = n16.view(B * S, Cc)
         do = op_gemm_nt(TO.cast_bf16(d2), TO.T2(W16(".proj_out.weight")))                       # [B*S, C] bf16
-        op_gemm_nt(TO.T2(d2), TO.T2(o), epilogue=2, C_inout=_g(P(".proj_out.weight")).view(Cc, Cc))
-        TO.colsum(d2, _g(P(".proj_out.bias")))
+        TO.lin_wgrad(d2, o, _g(P(".proj_out.weight")).view(Cc, Cc), _g(P(".proj_out.bias")))
         dP = torch.empty(B, S, S, device=x.device, dtype=torch.float32)
         TO.gemm2(do, Cc, S * Cc, 0, v, Cc, S * Cc, 0, dP, S, S * S, 0, S, S, Cc, B, 1, epilogue=1)
         delta = torch.empty(B, S, device=x.device, dtype=torch.float32)
@@ -251,10 +233,8 @@ class EncoderTrainer:
         dn = op_gemm_nt(dq, TO.T2(W16(".q.weight")), epilogue=1)
         op_gemm_nt(dk, TO.T2(W16(".k.weight")), epilogue=2, C_inout=dn)
         op_gemm_nt(dv, TO.T2(W16(".v.weight")), epilogue=2, C_inout=dn)
-        n2T = TO.T2(n2)
         for g, nm in ((dq, ".q"), (dk, ".k"), (dv, ".v")):
-            op_gemm_nt(TO.T2(g), n2T, epilogue=2, C_inout=_g(P(nm + ".weight")).view(Cc, Cc))
-            TO.colsum(g, _g(P(nm + ".bias")))
+            TO.lin_wgrad(g, n2, _g(P(nm + ".weight")).view(Cc, Cc), _g(P(nm + ".bias")))
         dx = dxo                                                                         # residual path
         groupnorm_bwd(x, st, P(".norm.weight").data, P(".norm.bias").data, dn.view(*x.shape), dx, _g(P(".norm.weight")), _g(P(".norm.bias")),
                       False, True)

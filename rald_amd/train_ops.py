@@ -21,7 +21,7 @@ from typing import Dict, Tuple
 
 import torch
 
-from ._handles import _ptr, _stream, op_attention, op_gemm_nt, op_layernorm
+from ._handles import _ptr, _stream, op_attention, op_gemm_nt, op_gemm_tn, op_layernorm
 from ._lib import check, lib
 
 HEAD = 64
@@ -73,6 +73,15 @@ def geglu_bwd(u: torch.Tensor, dhid: torch.Tensor) -> torch.Tensor:
     du = torch.empty_like(u)
     check(lib().rald_op_geglu_bwd(_p(u), _p(dhid), _p(du), u.shape[0], u.shape[1] // 2, C.c_void_p(_stream())))
     return du
+
+
+def lin_wgrad(dy: torch.Tensor, x_in: torch.Tensor, dW: torch.Tensor, dbias: torch.Tensor = None) -> None:
+    """dW [N1, N2] f32 += dy^T . x_in for dy [M, N1], x_in [M, N2] (bf16, or f32: cast first); dbias [N1] += column sums of dy."""
+    if dy.dtype != torch.bfloat16:
+        dy = cast_bf16(dy)
+    if x_in.dtype != torch.bfloat16:
+        x_in = cast_bf16(x_in)
+    op_gemm_tn(dy, x_in, dW, dbias)
 
 
 def colsum(x: torch.Tensor, out: torch.Tensor) -> None:
@@ -169,27 +178,26 @@ def block_backward(W, sv, dx: torch.Tensor, dmod: torch.Tensor = None, grads: Di
     ms = mod.stride(0)
 
     def lin_bwd(dy, x_in, name, bias=None):
-        """G[name] += dy^T . x_in (and G[bias] += column sums of dy)"""
+        """G[name] += dy^T . x_in (and G[bias] += column sums of dy): one launch of the row-contracting GEMM (csrc/gemm_tn.hip) on the
+        operands as they lie - no transposed copies, the bias gradient from the same pass"""
         if name not in G:
             G[name] = zeros(dy.shape[1], x_in.shape[1])
-        op_gemm_nt(T2(dy), T2(x_in), epilogue=2, C_inout=G[name])
-        if bias is not None:
-            if bias not in G:
-                G[bias] = zeros(dy.shape[1])
-            colsum(dy, G[bias])
+        if bias is not None and bias not in G:
+            G[bias] = zeros(dy.shape[1])
+        lin_wgrad(dy, x_in, G[name], G[bias] if bias is not None else None)
 
     def ada_bwd(j, x_saved, dh):
         ln_mod_bwd(x_saved, dh, mod[:, j, :D], ms, NL, 1.0, dx, dmod[:, j, :D], dmod[:, j, D:])
 
     # ---- feed-forward: x3 = x2 + hid.W2^T + b2 --------------------------------------------------------
     dxb = cast_bf16(dx)
-    lin_bwd(dx, sv["hid"], "w2", "b2")
+    lin_bwd(dxb, sv["hid"], "w2", "b2")
     du = geglu_bwd(sv["u"], op_gemm_nt(dxb, W["w2T"]))                              # [M, 4096]
     lin_bwd(du, sv["h3"], "w1", "b1")
     ada_bwd(2, sv["x2"], op_gemm_nt(du, W["w1T"], epilogue=1))
     # ---- cross-attention: x2 = x1 + o2.Wo2^T + bo2 ---------------------------------------------------
     dxb = cast_bf16(dx)
-    lin_bwd(dx, sv["o2"], "o2", "bo2")
+    lin_bwd(dxb, sv["o2"], "o2", "bo2")
     dO2 = op_gemm_nt(dxb, W["o2T"])
     dq2 = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
     dkc, dvc = torch.empty(Bn * T, D, device=dev, dtype=torch.bfloat16), torch.empty(Bn * T, D, device=dev, dtype=torch.bfloat16)
@@ -202,7 +210,7 @@ def block_backward(W, sv, dx: torch.Tensor, dmod: torch.Tensor = None, grads: Di
     ada_bwd(1, sv["x1"], op_gemm_nt(dq2, W["q2T"], epilogue=1))
     # ---- self-attention: x1 = x0 + o1.Wo^T + bo ------------------------------------------------------
     dxb = cast_bf16(dx)
-    lin_bwd(dx, sv["o1"], "o", "bo")
+    lin_bwd(dxb, sv["o1"], "o", "bo")
     dO1 = op_gemm_nt(dxb, W["oT"])
     qkv = sv["qkv"]
     dqkv = torch.empty_like(qkv)

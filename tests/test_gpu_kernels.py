@@ -206,6 +206,26 @@ def test_attention_row_major_v_transposed_lds_read(H):
     assert torch.equal(out, old)                                   # same arithmetic, different operand path
 
 
+@pytest.mark.parametrize("M,N1,N2", [(4096, 512, 512), (4096, 1536, 512), (1000, 136, 72), (512, 4096, 512), (70, 64, 1024)])
+def test_weight_gradient_gemm_contracts_over_rows(H, M, N1, N2):
+    """C += A^T.B for row-major A [M,N1], B [M,N2] (gemm_tn.hip: operands staged as they lie, fragments read transposed from LDS, the row
+    range split over workgroups, fp32 atomics) + the column sums of A: exact on small integers (pins the transposed-read lane mapping, the
+    ragged row tail and the column edges), against fp32 torch on random data, accumulating into a non-zero C, on column slices."""
+    A = _ints((M, N1 + 8), -3, 4, 31).cuda().bfloat16()[:, 8:]                # column slices of wider buffers
+    B = _ints((M, N2 + 16), -3, 4, 32).cuda().bfloat16()[:, :N2]
+    C0 = _ints((N1, N2), -5, 6, 33).cuda()
+    cs0 = _ints((N1,), -5, 6, 34).cuda()
+    Cm, cs = C0.clone(), cs0.clone()
+    H.op_gemm_tn(A, B, Cm, cs)
+    assert torch.equal(Cm, C0 + A.float().t() @ B.float())                    # |sums| < 2^24: exact in fp32 whatever the order
+    assert torch.equal(cs, cs0 + A.float().sum(0))
+    g = torch.Generator("cpu").manual_seed(35)
+    A = torch.randn(M, N1, generator=g).cuda().bfloat16(); B = torch.randn(M, N2, generator=g).cuda().bfloat16()
+    Cm = torch.zeros(N1, N2, device="cuda")
+    H.op_gemm_tn(A, B, Cm)
+    assert rel_l2(Cm, A.float().t() @ B.float()) < 2e-6
+
+
 def test_first_and_last_layer_small_and_large_row_forms():
     """proj_in (:221 + c_in) and final LayerNorm + proj_out + skip/out scaling (:230-232 + :429): both have a small-M and a large-M kernel
     (weights staged in LDS).  Each against fp64 torch, and the large form bit-equal to the small one on the same rows (same summation order)."""

@@ -38,7 +38,8 @@ def test_conv3d_forward_dgrad_wgrad_vs_autograd():
         dW, db = torch.zeros_like(Wt, device="cuda"), torch.zeros(Cout, device="cuda")
         TE.conv_wgrad(_cl(dy).cuda(), x16, dW, db)
         print("conv wgrad rel_l2", rel_l2(dW.cpu(), Wt.grad), rel_l2(db.cpu(), dy.sum((0, 2, 3, 4))))
-        assert rel_l2(dW.cpu(), Wt.grad) < 1e-2 and rel_l2(db.cpu(), dy.sum((0, 2, 3, 4))) < 1e-5
+        # (the bias gradient is the column sum of the bf16 copy of dy that feeds the MFMAs: ~1.5e-3, unbiased; it was an fp32 pass of its own)
+        assert rel_l2(dW.cpu(), Wt.grad) < 1e-2 and rel_l2(db.cpu(), dy.sum((0, 2, 3, 4))) < 5e-3
 
 
 def test_downsample_forward_dgrad_wgrad_vs_autograd():
