@@ -175,6 +175,179 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
         }
 }
 
+// =====================================================================================================================
+// Conv3d weight gradient, stride 1 / pad 1, line-staged: one workgroup = one (kd, kh) pair x one 64 x 64 (Cout x Cin) block of
+// the parameter x a range of output lines.  Per step it stages 64 output voxels (64 / W whole lines) of dy and the matching
+// INPUT lines (d + kd - 1, h + kh - 1) with a zero voxel on either side, and contracts them three times - the taps kw = 0, 1, 2
+// are the same LDS rows shifted by one.  The generic form above reads every input voxel 27 times and dy once per 128 patch
+// columns (11 GB from L2 for a 64 -> 64 convolution on 2.1 M voxels: 2 ms); this one reads both 9 times.
+// =====================================================================================================================
+struct WgradLineArgs {
+    const bf16* dy; const bf16* x; float* dW; float* dbias;
+    int D, H, W, lw, lh, ld, Cin, Cout, lines, steps_per_split, nsteps;   // lines = B*D*H; a step = 64 / W lines; lh / ld = log2(H), log2(D) or -1
+    int tiles;                                                            // 64 x 64 blocks of the parameter
+    int ablate;                                                           // probe builds (RALD_WGRAD_ABLATE): 1 no MFMA, 2 no LDS reads, 4 no DMA after the first stage, 8 no atomics
+};
+
+// 8-row DMA pieces sit 1152 bytes apart (1024 + 128): rows 8 apart - the row blocks of neighbouring lane groups of one transposed read -
+// then fall into different halves of the 256-byte bank row (with a plain 128-byte pitch all four groups hit the same banks).
+constexpr int WL_PIECE = 1152;
+// byte offset inside a 128-byte-pitch tile (64 columns) of the 8 bytes lane `lane` hands to ds_read_b64_tr_b16 for the 4-row block at
+// row r0 and the 16 columns at n0: row r0 + qq, columns n0 + 4 pp .. + 3; chunk ^ 2 (row & 3)
+__device__ __forceinline__ int wl_off(int r0, int n0, int lane) {
+    const int qq = (lane & 15) >> 2, pp = lane & 3;
+    const int c = (n0 >> 3) + (pp >> 1);
+    const int r = r0 + qq;
+    return (r >> 3) * WL_PIECE + (r & 7) * 128 + ((c ^ ((r & 3) << 1)) << 4) + 8 * (pp & 1);
+}
+__device__ __forceinline__ bf16x8 wl_read(const unsigned char* tile, int off_lo, int off_hi) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off_lo));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off_hi));
+    return __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_line_kernel(WgradLineArgs a) {
+    constexpr int A_BYTES = 8 * WL_PIECE, B_BYTES = 12 * WL_PIECE, STAGE = A_BYTES + B_BYTES, NST = 3;      // 64 dy rows, 96 input rows
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wa = wave >> 1, wb = wave & 1;                    // wave: 32 (Cout) x 32 (Cin) x 3 taps
+    // The 9 (kd, kh) workgroups of one (block, line range) read the same dy lines and overlapping input lines: keep them on ONE XCD
+    // (launch index g -> XCD g & 7), or each XCD fetches its own copy from HBM (4.8 GB per 64 -> 64 convolution on 2.1 M voxels, 1.25 ms).
+    // Slot g >> 3 of an XCD walks (kd, kh) fastest, then the block, then its share of the line ranges (range = 8 * k + XCD).
+    const int gl = blockIdx.x, xcd = gl & 7, slot = gl >> 3;
+    const int grp = slot % 9, rest = slot / 9;
+    const int tile_id = rest % a.tiles, split = (rest / a.tiles) * 8 + xcd;
+    const int kd = grp / 3, kh = grp % 3;
+    const int ncb = a.Cin >> 6;
+    const int co0 = (tile_id / ncb) * 64, ci0 = (tile_id % ncb) * 64;
+    const int W = a.W, Wp = W + 2, lps = 64 >> a.lw;            // lines per step
+    const int s_begin = split * a.steps_per_split;
+    int s_end = s_begin + a.steps_per_split;
+    if (s_end > a.nsteps) s_end = a.nsteps;
+    const int nst = s_end - s_begin;
+    if (nst <= 0) return;
+    const int prow = lane >> 3, pch = lane & 7;                 // DMA piece: 8 rows x 128 B
+    // 5 pieces per wave and stage: pieces 0..7 = dy rows, 8..19 = input rows (96; the unused ones read the zero line).  Everything that
+    // does not change from step to step is worked out here: the loop was bound by its own address arithmetic (2.2 us per step).
+    int64_t a_off[5];          // dy piece: element offset of this lane's 16 bytes relative to the step's first voxel; -1 = an input piece
+    int b_l[5], b_col[5];      // input piece: line inside the step (or -1: zero line) and element offset inside the input line
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+        const int piece = wave + 4 * p;
+        a_off[p] = -1; b_l[p] = -1; b_col[p] = 0;
+        if (piece < 8) {
+            const int r = 8 * piece + prow;
+            a_off[p] = (int64_t)r * a.Cout + co0 + (pch ^ ((r & 3) << 1)) * 8;
+        } else {
+            const int r = 8 * (piece - 8) + prow;
+            const int l = r / Wp, iwp = r - l * Wp;
+            if (l < lps && iwp >= 1 && iwp <= W) { b_l[p] = l; b_col[p] = (iwp - 1) * a.Cin + ci0 + (pch ^ ((r & 3) << 1)) * 8; }
+        }
+    }
+    auto stage = [&](int s, int buf) {
+        unsigned char* base = smem + buf * STAGE;
+        const int line0 = (s_begin + s) * lps;
+#pragma unroll
+        for (int p = 0; p < 5; ++p) {
+            const int piece = wave + 4 * p;
+            if (piece < 8) {                                     // (wave-uniform)
+                __builtin_amdgcn_global_load_lds((glb_void*)(a.dy + (int64_t)line0 * W * a.Cout + a_off[p]), (lds_void*)(base + piece * WL_PIECE), 16, 0, 0);
+            } else {
+                const bf16* src = g_tn_zero;
+                if (b_l[p] >= 0) {
+                    const int line = line0 + b_l[p];
+                    int h, d, b;
+                    if (a.lh >= 0) { h = line & (a.H - 1); d = (line >> a.lh) & (a.D - 1); b = line >> (a.lh + a.ld); }
+                    else { h = line % a.H; const int t = line / a.H; d = t % a.D; b = t / a.D; }
+                    const int id = d + kd - 1, ih = h + kh - 1;
+                    if ((unsigned)id < (unsigned)a.D && (unsigned)ih < (unsigned)a.H)
+                        src = a.x + (((int64_t)b * a.D + id) * a.H + ih) * W * a.Cin + b_col[p];
+                }
+                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(base + A_BYTES + (piece - 8) * WL_PIECE), 16, 0, 0);
+            }
+        }
+    };
+    // fragment read offsets (per lane, the same in every stage)
+    const int kq = lane >> 4;
+    int oa[2][2][2], ob[2][3][2][2];                            // [ks][i][lo/hi], [ks][tap][j][lo/hi]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int v0 = 32 * ks + 8 * kq;                         // this lane group's 8 voxels: two runs of 4 inside one line each
+        const int rb0 = (v0 >> a.lw) * Wp + (v0 & (W - 1)), rb1 = ((v0 + 4) >> a.lw) * Wp + ((v0 + 4) & (W - 1));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { oa[ks][i][0] = wl_off(v0, 32 * wa + 16 * i, lane); oa[ks][i][1] = wl_off(v0 + 4, 32 * wa + 16 * i, lane); }
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                ob[ks][t][j][0] = A_BYTES + wl_off(rb0 + t, 32 * wb + 16 * j, lane);
+                ob[ks][t][j][1] = A_BYTES + wl_off(rb1 + t, 32 * wb + 16 * j, lane);
+            }
+    }
+    f32x4 acc[3][2][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 csum[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const bool want_cs = a.dbias != nullptr && grp == 0 && ci0 == 0 && wb == 0;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+    stage(0, 0);
+    if (nst > 1) stage(1, 1);
+    int buf = 0;
+    for (int s = 0; s < nst; ++s) {
+        if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");     // the 5 pieces of stage s+1 may still be in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + 2 < nst && !RALD_ABLATED(a.ablate, 4)) stage(s + 2, buf >= 1 ? buf - 1 : NST - 1);          // (s + 2) % 3 == (buf + 2) % 3
+        const unsigned char* tS = smem + buf * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = RALD_ABLATED(a.ablate, 2) ? ones : wl_read(tS, oa[ks][i][0], oa[ks][i][1]);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bf16x8 fb = RALD_ABLATED(a.ablate, 2) ? ones : wl_read(tS, ob[ks][t][j][0], ob[ks][t][j][1]);
+                    if (RALD_ABLATED(a.ablate, 1)) { acc[t][0][j][0] += (float)fb[0] * (float)fa[0][1]; acc[t][1][j][1] += (float)fb[2] * (float)fa[1][3]; continue; }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[t][i][j], 0, 0, 0);
+                }
+            }
+            if (want_cs) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) csum[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], ones, csum[i], 0, 0, 0);
+            }
+        }
+        buf = buf + 1 < NST ? buf + 1 : 0;
+    }
+    // acc[t][i][j][e] = dW[co0 + 32 wa + 16 i + 4 (lane >> 4) + e][ci0 + 32 wb + 16 j + (lane & 15)][tap (kd, kh, t)]
+    if (RALD_ABLATED(a.ablate, 8) && acc[0][0][0][0] != 12345.f) return;
+    const int cl = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int co = co0 + 32 * wa + 16 * i + 4 * kq + e;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ci = ci0 + 32 * wb + 16 * j + cl;
+                float* dst = a.dW + ((int64_t)co * a.Cin + ci) * 27 + kd * 9 + kh * 3;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) unsafeAtomicAdd(dst + t, acc[t][i][j][e]);
+            }
+            if (want_cs && cl == 0) unsafeAtomicAdd(a.dbias + co, csum[i][e]);
+        }
+}
+
 static int tn_launch(GemmTnArgs a, bool conv, hipStream_t st) {
     const int t1 = cdiv(a.N1, 128), t2 = cdiv(a.N2, 128);
     // split the m range until ~1024 workgroups run, but keep at least 256 rows (4 k-steps) per split
@@ -215,10 +388,51 @@ int conv3d_wgrad_tn(const bf16* dy, const bf16* x, float* dW, float* dbias, int 
     const int OD = ID / stride, OH = IH / stride, OW = IW / stride;
     const int64_t M = (int64_t)B * OD * OH * OW;
     RALD_CHECK(M >= 1 && M < ((int64_t)1 << 31) && (int64_t)B * ID * IH * IW * Cin < ((int64_t)1 << 40), "conv3d_wgrad_tn: volume too large");
+    auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+    if (stride == 1 && pad == 1 && Cin % 64 == 0 && Cout % 64 == 0 && lg(IW) >= 2 && IW <= 64 && ((int64_t)B * ID * IH) % (64 / IW) == 0 &&
+        (int64_t)B * ID * IH < ((int64_t)1 << 30)) {
+        WgradLineArgs w;
+        w.dy = dy; w.x = x; w.dW = dW; w.dbias = dbias; w.D = ID; w.H = IH; w.W = IW; w.lw = lg(IW); w.Cin = Cin; w.Cout = Cout;
+        w.lh = lg(IH); w.ld = lg(ID);
+        if (w.lh < 0 || w.ld < 0) w.lh = w.ld = -1;
+        w.lines = B * ID * IH;
+        w.nsteps = w.lines / (64 / IW);
+        const int tiles = (Cin / 64) * (Cout / 64);
+        // Line ranges: a multiple of 8 (one per XCD and slot round), chosen so that the workgroups fill whole rounds of the chip's 512 slots
+        // (2 per CU) - 1 080 workgroups ran as two rounds and a third one 11 % full - and as few as that allows: every range ends in
+        // 64 x 64 x 3 atomics per workgroup (measured: a quarter of the kernel's time at 120 ranges).
+        int splits = 8;
+        {
+            double best = -1.0;
+            const int forced = RALD_PROBE_ENV("RALD_WGRAD_SPLITS", 0);
+            for (int r = 1; r <= 4; ++r) {
+                int sp = 8 * ((512 * r) / (72 * tiles));
+                if (sp < 8) sp = 8;
+                if (sp > (int)round_up(cdiv(w.nsteps, 8), 8)) sp = (int)round_up(cdiv(w.nsteps, 8), 8);
+                const int wgs = 9 * tiles * sp;
+                const double eff = (double)wgs / (double)(cdiv(wgs, 512) * 512);
+                if (eff > best + 0.05) { best = eff; splits = sp; }
+            }
+            if (forced > 0) splits = (int)round_up(forced, 8);
+        }
+        w.steps_per_split = cdiv(w.nsteps, splits);
+        splits = (int)round_up(cdiv(w.nsteps, w.steps_per_split), 8);          // (ranges past the last step return at once)
+        w.tiles = tiles;
+        w.ablate = RALD_PROBE_ENV("RALD_WGRAD_ABLATE", 0);
+        RALD_CHECK((int64_t)9 * tiles * splits < ((int64_t)1 << 31), "conv3d_wgrad_tn: grid too large");
+        constexpr int LDS = 3 * 20 * WL_PIECE;
+        static bool attr_set = false;
+        if (!attr_set) {
+            RALD_HIP(hipFuncSetAttribute((const void*)conv_wgrad_line_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(conv_wgrad_line_kernel, dim3(9 * tiles * splits), dim3(256), LDS, st, w);
+        RALD_HIP(hipGetLastError());
+        return 0;
+    }
     GemmTnArgs a = {};
     a.A = dy; a.lda = Cout; a.B = x; a.ldb = 0; a.C = dW; a.ldc = (int64_t)Cin * 27; a.colsum = dbias; a.M = (int)M; a.N1 = Cout; a.N2 = 27 * Cin;
     a.ID = ID; a.IH = IH; a.IW = IW; a.Cin = Cin; a.OD = OD; a.OH = OH; a.OW = OW; a.stride = stride; a.pad = pad;
-    auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
     a.lw = lg(OW); a.lh = lg(OH); a.ld = lg(OD);
     if (a.lw < 0 || a.lh < 0 || a.ld < 0) a.lw = a.lh = a.ld = -1;
     return tn_launch(a, true, st);
