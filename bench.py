@@ -227,10 +227,27 @@ def main():
         out["cpu_baseline"] = cpu_baseline_nfe(sd, depth)
     elif rank == 0:
         out["cpu_baseline"] = None
+    watchdog = None
     if not args.no_extras:
         # every rank runs these two legs on its own shard (frames / training samples are independent; the training step
         # exchanges gradients over RCCL); rank 0 reports the whole-job rates
         from rald_amd import bench_extras
+        if world > 1:
+            # The headline above is measured; the legs below exchange gradients over RCCL, which no run before the driver's own has
+            # exercised on more than one GPU.  If a collective ever hangs there, the headline line must still be printed: a watchdog
+            # prints it (legs marked as timed out) and ends the process.
+            import threading
+            limit = float(os.environ.get("RALD_BENCH_LEG_TIMEOUT", "600"))
+
+            def _bail():
+                if rank == 0:
+                    snap = dict(out)
+                    snap["secondary_legs"] = f"timed out after {limit:.0f} s (headline unaffected)"
+                    print(json.dumps(snap), flush=True)
+                os._exit(0)
+            watchdog = threading.Timer(limit, _bail)
+            watchdog.daemon = True
+            watchdog.start()
         for name, fn in (("config4", bench_extras.config4_leg), ("ddp_step", bench_extras.ddp_step_leg)):
             try:
                 barrier(world)
@@ -241,6 +258,8 @@ def main():
             except Exception as e:      # secondary legs never invalidate the headline line
                 out[name] = {"error": repr(e)}
             barrier(world)
+    if watchdog is not None:
+        watchdog.cancel()
     if rank == 0 and world == 1 and not args.no_extras:
         log("extras: sampler / AE timings")
         try:
