@@ -74,7 +74,9 @@ int64_t rald_dit_workspace_generation(const rald_dit* h);
  * depth*3 AdaLayerNorm modulations (:128-129) once; rald_dit_denoise refers to rows of it. */
 int rald_dit_set_sigmas(rald_dit* h, const float* sigmas_host, int32_t n, void* stream);
 
-/* Bytes of the per-batch condition cache (K and V^T of the condition tokens for every block). */
+/* Bytes of the condition cache FOR THIS BATCH SIZE (a cache is built for, and used with, one batch size): K and V^T of the condition
+ * tokens for every block, and from 3 samples up (bf16 mode) also the folded forms K.to_q and to_out.V^T per sample and block
+ * (1 MiB each) that turn the cross-attention sub-block into two GEMMs - not a linear function of `batch`, so always ask. */
 int64_t rald_dit_cond_cache_bytes(const rald_dit* h, int32_t batch);
 /* Condition tokens [B, n_cond_tokens, context_dim] -> cond cache (the K/V projections of
  * attn2 are step-invariant; CrossAttention.to_k/to_v :63-64). */
