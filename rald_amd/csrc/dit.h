@@ -67,6 +67,7 @@ struct Dit {
     float *w_mod = nullptr, *b_mod = nullptr;           // all AdaLN linears stacked: [(L*3)*2D, D] fp32
     float *w_t0 = nullptr, *b_t0 = nullptr, *w_t1 = nullptr, *b_t1 = nullptr;
     float *w_in = nullptr, *w_out = nullptr, *norm_g = nullptr, *norm_b = nullptr, *coef_raw = nullptr;
+    bf16* w_out_hl = nullptr;                           // proj_out weight split into bf16 hi | lo (final_norm_proj's large-M form), built at finalize
     int* d_geglu_map = nullptr;
     RadarEncoder radar;
     std::set<std::string> expected, loaded;

@@ -146,6 +146,7 @@ int Dit::create() {
     b_t1 = F32(D);
     w_in = F32((size_t)D * c.channels);
     w_out = F32((size_t)c.channels * D);
+    w_out_hl = B16((size_t)2 * c.channels * D);
     norm_g = F32(D);
     norm_b = F32(D);
     coef_raw = F32(4);
@@ -259,6 +260,8 @@ int Dit::finalize() {
         }
         RALD_HIP(hipDeviceSynchronize());
     }
+    RALD_TRY(split_hi_lo(w_out, w_out_hl, cfg.channels * D, nullptr));      // proj_out for the MFMA form of the output layer (norm.hip)
+    RALD_HIP(hipDeviceSynchronize());
     finalized = true;
     return 0;
 }
@@ -573,7 +576,7 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
             if (li + 1 < L) RALD_TRY(resid_ln8(ws_g, 4 * D, l.w_ff2, 4 * D, l.b_ff2, 4 * D, mod + (int64_t)((li + 1) * 3) * 2 * D));
             else RALD_TRY(resid_ln(ws_g, 4 * D, l.w_ff2, 4 * D, l.b_ff2, 4 * D, nullptr));
         }
-        RALD_TRY(final_norm_proj(ws_x, norm_g, norm_b, w_out, x, out, M, D, C, coef, cstride, NL, st));
+        RALD_TRY(final_norm_proj(ws_x, norm_g, norm_b, w_out, x, out, M, D, C, coef, cstride, NL, st, w_out_hl));
         return 0;
     }
     RALD_TRY(layernorm_mod(ws_x, ws_h, M, D, mod, mod + D, gstride, NL, 1.0f, 1e-5f, st));      // norm1 of block 0
@@ -653,7 +656,7 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
         const float* m1_next = (li + 1 < L) ? mod + (int64_t)((li + 1) * 3) * 2 * D : nullptr;   // norm1 of the next block
         RALD_TRY(resid_ln(ws_g, 4 * D, l.w_ff2, 4 * D, l.b_ff2, 4 * D, m1_next));
     }
-    RALD_TRY(final_norm_proj(ws_x, norm_g, norm_b, w_out, x, out, M, D, C, coef, cstride, NL, st));
+    RALD_TRY(final_norm_proj(ws_x, norm_g, norm_b, w_out, x, out, M, D, C, coef, cstride, NL, st, w_out_hl));
     return 0;
 }
 

@@ -83,7 +83,9 @@ int proj_in(const float* xin, const float* W, float* x, int M, int C, int D, con
 // D_x[m][c] = c_skip * xin[m][c] + c_out * sum_k LN_affine(x[m])[k] * Wout[c][k]
 int final_norm_proj(const float* x, const float* gamma, const float* beta, const float* Wout,
                     const float* xin, float* out, int M, int D, int C, const float* coef,
-                    int coef_stride, int rows_per_group, hipStream_t st);
+                    int coef_stride, int rows_per_group, hipStream_t st, const bf16* Whl = nullptr);
+// out [hi | lo][n] bf16 with w = hi + lo (to ~2^-17): the pre-split proj_out weight that final_norm_proj's large-M form takes as Whl
+int split_hi_lo(const float* w, bf16* out, int n, hipStream_t st);
 
 // ---------------------------------------------------------------- attention.hip
 struct AttnArgs {

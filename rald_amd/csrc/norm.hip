@@ -309,11 +309,144 @@ __global__ __launch_bounds__(256) void final_norm_proj_kernel(const float* __res
     }
 }
 
+// Large-M form on the matrix cores.  The one-row kernel above is VALU-bound (1.07 GFLOP of fp32 FMAs with their operand shuffles: 79 us at
+// 32 768 rows for a pass whose HBM traffic takes 10); here a workgroup normalises 32 rows into LDS as bf16 hi + lo (x = hi + lo to ~2^-17)
+// and multiplies them by the likewise split weight on v_mfma_f32_16x16x32_bf16 - hi.hi + lo.hi + hi.lo, fp32 accumulation - so the
+// output layer keeps fp32-grade accuracy (measured against fp64: see tests) while the multiply costs ~nothing.
+__global__ __launch_bounds__(256) void final_norm_proj_mfma_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, const float* __restrict__ Wout,
+                                                                   const float* __restrict__ xin, float* __restrict__ out, int M,
+                                                                   const float* __restrict__ coef, int coef_stride, int rows_per_group,
+                                                                   const bf16* __restrict__ Whl) {      // optional: the weight already split, [hi | lo][32][512]
+    constexpr int D = 512, C = 32, R = 32;
+    __shared__ __attribute__((aligned(16))) unsigned char sm[2 * R * D * 2];         // [hi | lo][32 rows][1 KiB], 16-byte chunk c of row n at c ^ (n & 15)
+    unsigned char* const thi = sm;
+    unsigned char* const tlo = sm + R * D * 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = blockIdx.x * R;
+    const float4 g0 = reinterpret_cast<const float4*>(gamma)[lane], g1 = reinterpret_cast<const float4*>(gamma)[lane + 64];
+    const float4 b0 = reinterpret_cast<const float4*>(beta)[lane], b1 = reinterpret_cast<const float4*>(beta)[lane + 64];
+    // ---- phase 1: LayerNorm(affine) of 8 rows per wave, split into bf16 hi + lo
+    float4 v[8][2];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int row = row0 + 8 * wave + r < M ? row0 + 8 * wave + r : M - 1;
+        const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * D);
+        v[r][0] = xr[lane]; v[r][1] = xr[lane + 64];
+    }
+    // (the 8 rows' reductions run side by side: 8 independent shuffle chains instead of 16 dependent ones in a row)
+    float mean8[8], rstd8[8];
+    {
+        float s8[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            s8[r] = 0.f;
+            s8[r] += v[r][0].x + v[r][0].y + v[r][0].z + v[r][0].w;
+            s8[r] += v[r][1].x + v[r][1].y + v[r][1].z + v[r][1].w;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) s8[r] += __shfl_xor(s8[r], o, 64);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            mean8[r] = s8[r] * (1.0f / D);
+            float q = 0.f;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float dx = v[r][c].x - mean8[r], dy = v[r][c].y - mean8[r], dz = v[r][c].z - mean8[r], dw = v[r][c].w - mean8[r];
+                q += dx * dx + dy * dy + dz * dz + dw * dw;
+            }
+            s8[r] = q;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) s8[r] += __shfl_xor(s8[r], o, 64);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) rstd8[r] = rsqrtf(s8[r] * (1.0f / D) + 1e-5f);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const float mean = mean8[r], rstd = rstd8[r];
+        const int rl = 8 * wave + r;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float4 gg = c ? g1 : g0, bb = c ? b1 : b0;
+            const float y0 = (v[r][c].x - mean) * rstd * gg.x + bb.x, y1 = (v[r][c].y - mean) * rstd * gg.y + bb.y;
+            const float y2 = (v[r][c].z - mean) * rstd * gg.z + bb.z, y3 = (v[r][c].w - mean) * rstd * gg.w + bb.w;
+            const bf16 h0 = (bf16)y0, h1 = (bf16)y1, h2 = (bf16)y2, h3 = (bf16)y3;
+            const int col = 256 * c + 4 * lane;                       // 4 consecutive columns = half a 16-byte chunk
+            const int off = rl * 1024 + ((((col >> 3) ^ (rl & 15))) << 4) + ((col >> 2) & 1) * 8;
+            bf16x4 hv, lv;
+            hv[0] = h0; hv[1] = h1; hv[2] = h2; hv[3] = h3;
+            lv[0] = (bf16)(y0 - (float)h0); lv[1] = (bf16)(y1 - (float)h1); lv[2] = (bf16)(y2 - (float)h2); lv[3] = (bf16)(y3 - (float)h3);
+            *reinterpret_cast<bf16x4*>(thi + off) = hv;
+            *reinterpret_cast<bf16x4*>(tlo + off) = lv;
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: out tile [16 rows rt][16 channels ct] per wave
+    const int rt = wave >> 1, ct = wave & 1, i = lane & 15, kq = lane >> 4;
+    const int arow = 16 * rt + i;
+    const float* wp = Wout + (int64_t)(16 * ct + i) * D + 8 * kq;
+    const bf16* wh = Whl ? Whl + (int64_t)(16 * ct + i) * D + 8 * kq : nullptr;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {                              // (fully unrolled: all 32 weight fragments of the wave in flight at once)
+        bf16x8 bh, bl;
+        if (wh) {
+            bh = *reinterpret_cast<const bf16x8*>(wh + 32 * ks);
+            bl = *reinterpret_cast<const bf16x8*>(wh + C * D + 32 * ks);
+        } else {
+            const float4 w0 = *reinterpret_cast<const float4*>(wp + 32 * ks), w1 = *reinterpret_cast<const float4*>(wp + 32 * ks + 4);
+            const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { bh[e] = (bf16)wv[e]; bl[e] = (bf16)(wv[e] - (float)bh[e]); }
+        }
+        const int aoff = arow * 1024 + (((4 * ks + kq) ^ (arow & 15)) << 4);
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(thi + aoff), al = *reinterpret_cast<const bf16x8*>(tlo + aoff);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+    }
+    // acc[e] = F[row0 + 16 rt + 4 kq + e][16 ct + i]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int row = row0 + 16 * rt + 4 * kq + e;
+        if (row < M) {
+            const float* cf = coef + (int64_t)(row / rows_per_group) * coef_stride;
+            const int64_t o = (int64_t)row * C + 16 * ct + i;
+            out[o] = cf[1] * xin[o] + cf[2] * acc[e];
+        }
+    }
+}
+
+// Wout [C][512] fp32 -> bf16 [hi | lo][C][512] (x = hi + lo to ~2^-17): the large-M kernel's B operand, once per weight load
+__global__ void split_hi_lo_kernel(const float* __restrict__ w, bf16* __restrict__ out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const bf16 h = (bf16)w[i];
+    out[i] = h;
+    out[n + i] = (bf16)(w[i] - (float)h);
+}
+int split_hi_lo(const float* w, bf16* out, int n, hipStream_t st) {
+    hipLaunchKernelGGL(split_hi_lo_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, w, out, n);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
 int final_norm_proj(const float* x, const float* gamma, const float* beta, const float* Wout,
                     const float* xin, float* out, int M, int D, int C, const float* coef,
-                    int coef_stride, int rows_per_group, hipStream_t st) {
+                    int coef_stride, int rows_per_group, hipStream_t st, const bf16* Whl) {
     RALD_CHECK(C >= 1 && C <= 64, "final_norm_proj: output channels must be in [1,64]");
     RALD_CHECK(D == 512, "final_norm_proj: D must be 512");
+    if (C == 32 && M >= 8192) {
+        hipLaunchKernelGGL(final_norm_proj_mfma_kernel, dim3(cdiv(M, 32)), dim3(256), 0, st, x, gamma, beta, Wout, xin, out, M, coef, coef_stride,
+                           rows_per_group, Whl);
+        RALD_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL((final_norm_proj_kernel<8>), dim3(cdiv(M, 4)), dim3(256), 0, st, x, gamma, beta, Wout, xin, out, M, C,
                        coef, coef_stride, rows_per_group);
     RALD_HIP(hipGetLastError());
