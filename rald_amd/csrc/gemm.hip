@@ -688,6 +688,10 @@ static int gemm_nt_impl(const GemmArgs& a, int epi, hipStream_t st) {
             return launch_geglu_persist(a, st);
 #endif
         if (a.M % 256 == 0 && a.N % 256 == 0 && wg256 >= 256) return launch_glds<256, 256, 4, 2, 2>(a, epi, st);
+        // 192-320 tiles of 128 x 128 = about one 4-wave workgroup per CU, walking its k-steps as a latency chain (N = 512 projections at
+        // M = 8192: 19-21 us for 4.3 GFLOP).  64 x 128 tiles with 3 stages give two workgroups per CU and a deeper prefetch: NFE at
+        // B = 16 4.63 -> 4.36 ms, B = 8 2.94 -> 2.90 ms (RALD_GEMM_64x128=0 in probe builds: the old choice).
+        if (epi != EPI_SOFTMAX64 && epi != EPI_GEGLU && wg128 <= RALD_PROBE_ENV("RALD_GEMM_64x128_MAX", 320) && a.M % 64 == 0 && RALD_PROBE_ENV("RALD_GEMM_64x128", 1)) return launch_glds<64, 128, 2, 2, 3>(a, epi, st);
         return launch_glds<128, 128, 2, 2, 2>(a, epi, st);
     }
     switch (impl) {
