@@ -669,7 +669,7 @@ static int gemm_nt_impl(const GemmArgs& a, int epi, hipStream_t st) {
     int impl = -1;
     impl = RALD_PROBE_ENV("RALD_GEMM_IMPL", -1);
     const int64_t wg128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) * nbatch;
-    if (wg128 < 192) {
+    if (wg128 < RALD_PROBE_ENV("RALD_GEMM_SMALL_MAX", 192)) {
         // small-M (batch-1) regime: too few tiles to hide memory latency behind other workgroups, so put
         // (up to) the whole K extent in flight at once: 64x64 tiles, 8-stage LDS-DMA ring (128 KB).
         const int64_t wg64 = (int64_t)cdiv(a.M, 64) * cdiv(a.N, 64) * nbatch;
