@@ -262,6 +262,9 @@ int rald_op_gemm_tn(const void* A_bf16, int64_t lda, const void* B_bf16, int64_t
  * of dy.  dy [B*OD*OH*OW][Cout] bf16, x [B][ID][IH][IW][Cin] bf16 channels-last, OD = ID / stride ... */
 int rald_op_conv3d_wgrad(const void* dy_bf16, const void* x_bf16, float* dW, float* dbias, int32_t B, int32_t ID, int32_t IH, int32_t IW, int32_t Cin,
                          int32_t Cout, int32_t stride, int32_t pad, void* stream);
+/* conv_in (one input channel) weight gradient, first half: the 27-neighbourhood of channel 0 of cube [B][D][H][W][cube_ch] fp32 per voxel as one
+ * bf16 row of 32 (taps kd*9 + kh*3 + kw, zero outside the volume, 5 zero pads); dW = rald_op_gemm_tn(dy, patches). */
+int rald_op_patches27(const float* cube, int32_t cube_ch, void* out_bf16, int32_t B, int32_t D, int32_t H, int32_t W, void* stream);
 int rald_op_transpose(const void* in, int32_t in_is_bf16, int64_t ld_in, int64_t stride_in, int64_t stride_in2, void* out_bf16, int64_t ld_out,
                       int64_t stride_out, int64_t stride_out2, int32_t rows, int32_t cols, int32_t batch, int32_t batch2, void* stream);
 /* AdaLayerNorm :119-131 (add_one = 1) / LayerNorm (add_one = 0, scale = weight) backward, D = 512:

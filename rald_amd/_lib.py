@@ -118,6 +118,7 @@ SIGNATURES = {
     "rald_op_ae_decode_tables": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rald_op_gemm_tn": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_void_p]),
     "rald_op_conv3d_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rald_op_patches27": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "rald_op_proj_in": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "rald_op_final_norm_proj": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "rald_op_ae_encode_tables": (c_int, [c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

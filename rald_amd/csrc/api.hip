@@ -275,6 +275,9 @@ int rald_op_conv3d_wgrad(const void* dy_bf16, const void* x_bf16, float* dW, flo
                          int32_t Cout, int32_t stride, int32_t pad, void* stream) {
     return conv3d_wgrad_tn((const bf16*)dy_bf16, (const bf16*)x_bf16, dW, dbias, B, ID, IH, IW, Cin, Cout, stride, pad, (hipStream_t)stream);
 }
+int rald_op_patches27(const float* cube, int32_t cube_ch, void* out_bf16, int32_t B, int32_t D, int32_t H, int32_t W, void* stream) {
+    return patches27(cube, cube_ch, (bf16*)out_bf16, B, D, H, W, (hipStream_t)stream);
+}
 int rald_op_transpose(const void* in, int32_t in_is_bf16, int64_t ld_in, int64_t stride_in, int64_t stride_in2, void* out_bf16, int64_t ld_out,
                       int64_t stride_out, int64_t stride_out2, int32_t rows, int32_t cols, int32_t batch, int32_t batch2, void* stream) {
     TransposeArgs a;

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
 // =====================================================================================================================
 struct WgradLineArgs {
     const bf16* dy; const bf16* x; float* dW; float* dbias;
-    int D, H, W, lw, lh, ld, Cin, Cout, lines, steps_per_split, nsteps;   // lines = B*D*H; a step = 64 / W lines; lh / ld = log2(H), log2(D) or -1
+    int D, H, W, lw, lh, ld, Cin, Cout, lines, steps_per_split, nsteps;   // OUTPUT dims; lines = B*D*H; a step = 64 / W lines; lh / ld = log2(H), log2(D) or -1
     int tiles;                                                            // 64 x 64 blocks of the parameter
     int ablate;                                                           // probe builds (RALD_WGRAD_ABLATE): 1 no MFMA, 2 no LDS reads, 4 no DMA after the first stage, 8 no atomics
 };
@@ -194,10 +194,10 @@ struct WgradLineArgs {
 constexpr int WL_PIECE = 1152;
 // byte offset inside a 128-byte-pitch tile (64 columns) of the 8 bytes lane `lane` hands to ds_read_b64_tr_b16 for the 4-row block at
 // row r0 and the 16 columns at n0: row r0 + qq, columns n0 + 4 pp .. + 3; chunk ^ 2 (row & 3)
-__device__ __forceinline__ int wl_off(int r0, int n0, int lane) {
+__device__ __forceinline__ int wl_off(int r0, int n0, int lane, int rstep = 1) {
     const int qq = (lane & 15) >> 2, pp = lane & 3;
     const int c = (n0 >> 3) + (pp >> 1);
-    const int r = r0 + qq;
+    const int r = r0 + rstep * qq;
     return (r >> 3) * WL_PIECE + (r & 7) * 128 + ((c ^ ((r & 3) << 1)) << 4) + 8 * (pp & 1);
 }
 __device__ __forceinline__ bf16x8 wl_read(const unsigned char* tile, int off_lo, int off_hi) {
@@ -206,8 +206,15 @@ __device__ __forceinline__ bf16x8 wl_read(const unsigned char* tile, int off_lo,
     return __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// S = 1: stride 1, pad 1 (input dims = output dims; input rows of a line: W + 2, a zero voxel on either side).
+// S = 2: Downsample (stride 2 over the input padded by one voxel at the far ends, models_radar_encoder.py:37-41): input dims = 2 x output
+// dims, input voxel (2 d + kd, 2 h + kh, 2 w + kw), out of range only at index 2 W; 2 W + 1 input rows per line, the four voxels of a
+// transposed read are two rows apart.
+template <int S>
 __global__ __launch_bounds__(256) void conv_wgrad_line_kernel(WgradLineArgs a) {
-    constexpr int A_BYTES = 8 * WL_PIECE, B_BYTES = 12 * WL_PIECE, STAGE = A_BYTES + B_BYTES, NST = 3;      // 64 dy rows, 96 input rows
+    constexpr int PB = S == 1 ? 12 : 20;                        // 8-row pieces of the input tile: 96 / 160 rows (>= 64 / W lines of W + 2 / 2 W + 1 rows)
+    constexpr int PPW = (8 + PB) / 4;                           // DMA pieces per wave and stage: 5 / 7
+    constexpr int A_BYTES = 8 * WL_PIECE, B_BYTES = PB * WL_PIECE, STAGE = A_BYTES + B_BYTES, NST = S == 1 ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -221,7 +228,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_line_kernel(WgradLineArgs a) {
     const int kd = grp / 3, kh = grp % 3;
     const int ncb = a.Cin >> 6;
     const int co0 = (tile_id / ncb) * 64, ci0 = (tile_id % ncb) * 64;
-    const int W = a.W, Wp = W + 2, lps = 64 >> a.lw;            // lines per step
+    const int W = a.W, Wp = S == 1 ? W + 2 : 2 * W + 1, lps = 64 >> a.lw;            // output width, input rows per line, lines per step
+    const int ID = S * a.D, IH = S * a.H, IW = S * W;
     const int s_begin = split * a.steps_per_split;
     int s_end = s_begin + a.steps_per_split;
     if (s_end > a.nsteps) s_end = a.nsteps;
@@ -230,10 +238,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_line_kernel(WgradLineArgs a) {
     const int prow = lane >> 3, pch = lane & 7;                 // DMA piece: 8 rows x 128 B
     // 5 pieces per wave and stage: pieces 0..7 = dy rows, 8..19 = input rows (96; the unused ones read the zero line).  Everything that
     // does not change from step to step is worked out here: the loop was bound by its own address arithmetic (2.2 us per step).
-    int64_t a_off[5];          // dy piece: element offset of this lane's 16 bytes relative to the step's first voxel; -1 = an input piece
-    int b_l[5], b_col[5];      // input piece: line inside the step (or -1: zero line) and element offset inside the input line
+    int64_t a_off[PPW];        // dy piece: element offset of this lane's 16 bytes relative to the step's first voxel; -1 = an input piece
+    int b_l[PPW], b_col[PPW];  // input piece: line inside the step (or -1: zero line) and element offset inside the input line
 #pragma unroll
-    for (int p = 0; p < 5; ++p) {
+    for (int p = 0; p < PPW; ++p) {
         const int piece = wave + 4 * p;
         a_off[p] = -1; b_l[p] = -1; b_col[p] = 0;
         if (piece < 8) {
@@ -242,14 +250,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_line_kernel(WgradLineArgs a) {
         } else {
             const int r = 8 * (piece - 8) + prow;
             const int l = r / Wp, iwp = r - l * Wp;
-            if (l < lps && iwp >= 1 && iwp <= W) { b_l[p] = l; b_col[p] = (iwp - 1) * a.Cin + ci0 + (pch ^ ((r & 3) << 1)) * 8; }
+            const int iw = S == 1 ? iwp - 1 : iwp;
+            if (l < lps && iw >= 0 && iw < IW) { b_l[p] = l; b_col[p] = iw * a.Cin + ci0 + (pch ^ ((r & 3) << 1)) * 8; }
         }
     }
     auto stage = [&](int s, int buf) {
         unsigned char* base = smem + buf * STAGE;
         const int line0 = (s_begin + s) * lps;
 #pragma unroll
-        for (int p = 0; p < 5; ++p) {
+        for (int p = 0; p < PPW; ++p) {
             const int piece = wave + 4 * p;
             if (piece < 8) {                                     // (wave-uniform)
                 __builtin_amdgcn_global_load_lds((glb_void*)(a.dy + (int64_t)line0 * W * a.Cout + a_off[p]), (lds_void*)(base + piece * WL_PIECE), 16, 0, 0);
@@ -260,9 +269,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_line_kernel(WgradLineArgs a) {
                     int h, d, b;
                     if (a.lh >= 0) { h = line & (a.H - 1); d = (line >> a.lh) & (a.D - 1); b = line >> (a.lh + a.ld); }
                     else { h = line % a.H; const int t = line / a.H; d = t % a.D; b = t / a.D; }
-                    const int id = d + kd - 1, ih = h + kh - 1;
-                    if ((unsigned)id < (unsigned)a.D && (unsigned)ih < (unsigned)a.H)
-                        src = a.x + (((int64_t)b * a.D + id) * a.H + ih) * W * a.Cin + b_col[p];
+                    const int id = S == 1 ? d + kd - 1 : 2 * d + kd, ih = S == 1 ? h + kh - 1 : 2 * h + kh;
+                    if ((unsigned)id < (unsigned)ID && (unsigned)ih < (unsigned)IH)
+                        src = a.x + (((int64_t)b * ID + id) * IH + ih) * IW * a.Cin + b_col[p];
                 }
                 __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(base + A_BYTES + (piece - 8) * WL_PIECE), 16, 0, 0);
             }
@@ -274,15 +283,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_line_kernel(WgradLineArgs a) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         const int v0 = 32 * ks + 8 * kq;                         // this lane group's 8 voxels: two runs of 4 inside one line each
-        const int rb0 = (v0 >> a.lw) * Wp + (v0 & (W - 1)), rb1 = ((v0 + 4) >> a.lw) * Wp + ((v0 + 4) & (W - 1));
+        const int rb0 = (v0 >> a.lw) * Wp + S * (v0 & (W - 1)), rb1 = ((v0 + 4) >> a.lw) * Wp + S * ((v0 + 4) & (W - 1));
 #pragma unroll
         for (int i = 0; i < 2; ++i) { oa[ks][i][0] = wl_off(v0, 32 * wa + 16 * i, lane); oa[ks][i][1] = wl_off(v0 + 4, 32 * wa + 16 * i, lane); }
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                ob[ks][t][j][0] = A_BYTES + wl_off(rb0 + t, 32 * wb + 16 * j, lane);
-                ob[ks][t][j][1] = A_BYTES + wl_off(rb1 + t, 32 * wb + 16 * j, lane);
+                ob[ks][t][j][0] = A_BYTES + wl_off(rb0 + t, 32 * wb + 16 * j, lane, S);
+                ob[ks][t][j][1] = A_BYTES + wl_off(rb1 + t, 32 * wb + 16 * j, lane, S);
             }
     }
     f32x4 acc[3][2][2];
@@ -298,14 +307,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_line_kernel(WgradLineArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
     stage(0, 0);
-    if (nst > 1) stage(1, 1);
+    if (NST == 3 && nst > 1) stage(1, 1);
     int buf = 0;
     for (int s = 0; s < nst; ++s) {
-        if (s + 1 < nst) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");     // the 5 pieces of stage s+1 may still be in flight
+        // three stages: the pieces of stage s+1 may still be in flight; two stages: nothing is (stage s+1 is issued below)
+        if (NST == 3 && s + 1 < nst) { if (S == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (s + 2 < nst && !RALD_ABLATED(a.ablate, 4)) stage(s + 2, buf >= 1 ? buf - 1 : NST - 1);          // (s + 2) % 3 == (buf + 2) % 3
+        if (s + NST - 1 < nst && !RALD_ABLATED(a.ablate, 4)) stage(s + NST - 1, buf >= 1 ? buf - 1 : NST - 1);          // (s + NST - 1) % NST
         const unsigned char* tS = smem + buf * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -389,14 +399,15 @@ int conv3d_wgrad_tn(const bf16* dy, const bf16* x, float* dW, float* dbias, int 
     const int64_t M = (int64_t)B * OD * OH * OW;
     RALD_CHECK(M >= 1 && M < ((int64_t)1 << 31) && (int64_t)B * ID * IH * IW * Cin < ((int64_t)1 << 40), "conv3d_wgrad_tn: volume too large");
     auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
-    if (stride == 1 && pad == 1 && Cin % 64 == 0 && Cout % 64 == 0 && lg(IW) >= 2 && IW <= 64 && ((int64_t)B * ID * IH) % (64 / IW) == 0 &&
-        (int64_t)B * ID * IH < ((int64_t)1 << 30)) {
+    const bool s1 = stride == 1 && pad == 1, s2 = stride == 2 && pad == 0 && ID % 2 == 0 && IH % 2 == 0 && IW % 2 == 0;
+    if ((s1 || s2) && Cin % 64 == 0 && Cout % 64 == 0 && lg(OW) >= 2 && OW <= 64 && ((int64_t)B * OD * OH) % (64 / OW) == 0 &&
+        (int64_t)B * OD * OH < ((int64_t)1 << 30)) {
         WgradLineArgs w;
-        w.dy = dy; w.x = x; w.dW = dW; w.dbias = dbias; w.D = ID; w.H = IH; w.W = IW; w.lw = lg(IW); w.Cin = Cin; w.Cout = Cout;
-        w.lh = lg(IH); w.ld = lg(ID);
+        w.dy = dy; w.x = x; w.dW = dW; w.dbias = dbias; w.D = OD; w.H = OH; w.W = OW; w.lw = lg(OW); w.Cin = Cin; w.Cout = Cout;
+        w.lh = lg(OH); w.ld = lg(OD);
         if (w.lh < 0 || w.ld < 0) w.lh = w.ld = -1;
-        w.lines = B * ID * IH;
-        w.nsteps = w.lines / (64 / IW);
+        w.lines = B * OD * OH;
+        w.nsteps = w.lines / (64 / OW);
         const int tiles = (Cin / 64) * (Cout / 64);
         // Line ranges: a multiple of 8 (one per XCD and slot round), chosen so that the workgroups fill whole rounds of the chip's 512 slots
         // (2 per CU) - 1 080 workgroups ran as two rounds and a third one 11 % full - and as few as that allows: every range ends in
@@ -420,13 +431,15 @@ int conv3d_wgrad_tn(const bf16* dy, const bf16* x, float* dW, float* dbias, int 
         w.tiles = tiles;
         w.ablate = RALD_PROBE_ENV("RALD_WGRAD_ABLATE", 0);
         RALD_CHECK((int64_t)9 * tiles * splits < ((int64_t)1 << 31), "conv3d_wgrad_tn: grid too large");
-        constexpr int LDS = 3 * 20 * WL_PIECE;
+        constexpr int LDS1 = 3 * 20 * WL_PIECE, LDS2 = 2 * 28 * WL_PIECE;
         static bool attr_set = false;
         if (!attr_set) {
-            RALD_HIP(hipFuncSetAttribute((const void*)conv_wgrad_line_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+            RALD_HIP(hipFuncSetAttribute((const void*)conv_wgrad_line_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS1));
+            RALD_HIP(hipFuncSetAttribute((const void*)conv_wgrad_line_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
             attr_set = true;
         }
-        hipLaunchKernelGGL(conv_wgrad_line_kernel, dim3(9 * tiles * splits), dim3(256), LDS, st, w);
+        if (s1) hipLaunchKernelGGL(conv_wgrad_line_kernel<1>, dim3(9 * tiles * splits), dim3(256), LDS1, st, w);
+        else hipLaunchKernelGGL(conv_wgrad_line_kernel<2>, dim3(9 * tiles * splits), dim3(256), LDS2, st, w);
         RALD_HIP(hipGetLastError());
         return 0;
     }

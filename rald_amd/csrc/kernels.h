@@ -66,6 +66,8 @@ int gemm_resid_ln(const GemmLnArgs& a, hipStream_t st);
 // whole-NFE sweeps: wins from M = 16384 on for K = 512 and K = 2048, +1 % per NFE at B = 32; at M = 8192 it loses)
 inline bool gemm_resid_ln_pays(int M, int K = 512) { (void)K; return M >= 16384; }
 
+// radar_train.hip: out [B*D*H*W][32] bf16 = the 27-neighbourhood (zero outside the volume) of channel 0 of cube [B][D][H][W][cube_ch], 5 zero pads
+int patches27(const float* cube, int cube_ch, bf16* out, int B, int D, int H, int Wd, hipStream_t st);
 // ---------------------------------------------------------------- gemm_tn.hip
 // C[n1][n2] += sum_m A[m][n1] . B[m][n2] (fp32, atomics); colsum (optional) [n1] += sum_m A[m][n1].  Weight / bias gradient of a Linear.
 int gemm_tn(const bf16* A, int64_t lda, const bf16* B, int64_t ldb, float* C, int64_t ldc, float* colsum, int M, int N1, int N2, hipStream_t st);

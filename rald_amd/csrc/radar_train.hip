@@ -119,6 +119,41 @@ int im2col_t(const bf16* x, bf16* out, int B, int ID, int IH, int IW, int C, int
     return 0;
 }
 
+// conv_in (Cin = 1) weight gradient as a row-contracting GEMM (gemm_tn.hip): the 27-neighbourhood of every voxel of the single input channel
+// as one bf16 row of 32 (27 taps + 5 zeros) - 134 MB for 2.1 M voxels - then dW [Cout][27] = dy^T . patches.  conv_in_wgrad_kernel below
+// (one serial pass per workgroup over its voxels, LDS-staged) takes 1.74 ms for 3.6 GFLOP; this pair ~0.15 ms.
+__global__ __launch_bounds__(256) void patches27_kernel(const float* __restrict__ cube, int cube_ch, bf16* __restrict__ out, int D, int H, int Wd, int64_t nvox) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t v = gid >> 2;                                   // 4 threads per voxel, 8 slots each
+    const int q = (int)(gid & 3);
+    if (v >= nvox) return;
+    const int w = (int)(v % Wd);
+    int64_t r = v / Wd;
+    const int h = (int)(r % H); r /= H;
+    const int d = (int)(r % D);
+    const int64_t b = r / D;
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int t = 8 * q + i;
+        float x = 0.f;
+        if (t < 27) {
+            const int id = d + t / 9 - 1, ih = h + (t / 3) % 3 - 1, iw = w + t % 3 - 1;
+            if ((unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)Wd)
+                x = cube[((((b * D + id) * H + ih) * Wd + iw)) * cube_ch];
+        }
+        o[i] = (bf16)x;
+    }
+    reinterpret_cast<bf16x8*>(out)[gid] = o;
+}
+int patches27(const float* cube, int cube_ch, bf16* out, int B, int D, int H, int Wd, hipStream_t st) {
+    RALD_CHECK(cube && out && B >= 1 && cube_ch >= 1, "patches27: bad arguments");
+    const int64_t nvox = (int64_t)B * D * H * Wd;
+    hipLaunchKernelGGL(patches27_kernel, dim3((unsigned)cdiv(nvox * 4, (int64_t)256)), dim3(256), 0, st, cube, cube_ch, out, D, H, Wd, nvox);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
 // conv_in (Cin = 1): dW[co][t] += sum_v dY[v][co] * cube[v + off(t)][0].  A workgroup walks `chunks` tiles of 256
 // voxels (neighbourhoods staged in LDS), thread (co, tap group) keeps 7 partial sums, one atomicAdd per output per
 // workgroup.  Cout <= 64.

@@ -315,5 +315,9 @@ class EncoderTrainer:
             elif kind == "conv_in":
                 cube = rec[1]
                 Bc, R, A, E, cch = cube.shape
-                check(lib().rald_op_conv_in_wgrad(_p(cube), cch, _p(dx), Bc, R, A, E, self.ch, _p(_g(self.p("conv_in.weight"))), _st()))
-                TO.colsum(dx.view(-1, self.ch), _g(self.p("conv_in.bias")))
+                # dW [ch][1][27] = dy^T . patches (27-neighbourhoods of the one input channel as bf16 rows of 32), dbias from the same launch
+                pat = torch.empty(Bc * R * A * E, 32, device=cube.device, dtype=torch.bfloat16)
+                check(lib().rald_op_patches27(_p(cube), cch, _p(pat), Bc, R, A, E, _st()))
+                dw32 = torch.zeros(self.ch, 32, device=cube.device, dtype=torch.float32)
+                TO.lin_wgrad(dx.view(-1, self.ch), pat, dw32, _g(self.p("conv_in.bias")))
+                _g(self.p("conv_in.weight")).view(self.ch, 27).add_(dw32[:, :27])

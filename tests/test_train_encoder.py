@@ -42,9 +42,9 @@ def test_conv3d_forward_dgrad_wgrad_vs_autograd():
         assert rel_l2(dW.cpu(), Wt.grad) < 1e-2 and rel_l2(db.cpu(), dy.sum((0, 2, 3, 4))) < 5e-3
 
 
-def test_downsample_forward_dgrad_wgrad_vs_autograd():
+@pytest.mark.parametrize("B,D,H,W,Cc", [(2, 8, 4, 4, 64), (2, 8, 8, 16, 64)])      # output width 2: generic weight-gradient kernel; 8: the line-staged stride-2 form
+def test_downsample_forward_dgrad_wgrad_vs_autograd(B, D, H, W, Cc):
     from rald_amd import train_encoder as TE
-    B, D, H, W, Cc = 2, 8, 4, 4, 64
     x = synth.normal([B, Cc, D, H, W], 610).bfloat16().float().requires_grad_()
     Wt = (synth.normal([Cc, Cc, 3, 3, 3], 611) / (Cc * 27) ** 0.5).requires_grad_()
     b = synth.normal([Cc], 612) * 0.1
@@ -58,10 +58,10 @@ def test_downsample_forward_dgrad_wgrad_vs_autograd():
     dx = TE.down_dgrad(_cl(dy).cuda(), Wt.detach().cuda())
     print("downsample dgrad rel_l2", rel_l2(_cf(dx.cpu()), x.grad))
     assert rel_l2(_cf(dx.cpu()), x.grad) < 1e-2
-    dW = torch.zeros_like(Wt, device="cuda")
-    TE.conv_wgrad(_cl(dy).cuda(), x16, dW, None, stride=2, pad=0)
-    print("downsample wgrad rel_l2", rel_l2(dW.cpu(), Wt.grad))
-    assert rel_l2(dW.cpu(), Wt.grad) < 1e-2
+    dW, db = torch.zeros_like(Wt, device="cuda"), torch.zeros(Cc, device="cuda")
+    TE.conv_wgrad(_cl(dy).cuda(), x16, dW, db, stride=2, pad=0)
+    print("downsample wgrad rel_l2", rel_l2(dW.cpu(), Wt.grad), rel_l2(db.cpu(), dy.sum((0, 2, 3, 4))))
+    assert rel_l2(dW.cpu(), Wt.grad) < 1e-2 and rel_l2(db.cpu(), dy.sum((0, 2, 3, 4))) < 5e-3
 
 
 def test_groupnorm_swish_forward_backward_vs_autograd():
