@@ -29,6 +29,7 @@ struct GemmTnArgs {
     float* C; int64_t ldc;           // [N1][N2] fp32, accumulated into
     float* colsum;                   // optional [N1]: += sum_m A[m][n1] (the bias gradient of the same Linear)
     int M, N1, N2, rows_per_split;
+    int t1, t2;                      // 128-wide tiles along n1, n2 (1-D launch: see the kernel)
     // CONV form (weight gradient of a 3x3x3 Conv3d, channels-last input x [B][ID][IH][IW][Cin]): row m = output voxel, column
     // n2 = tap * Cin + ci of the VIRTUAL patch matrix B[m][n2] = x[b][od*s - p + kd][oh*s - p + kh][ow*s - p + kw][ci] (zero outside);
     // C is the parameter's own [Cout][Cin][27] layout: output column n2 lands at ci * 27 + tap.
@@ -62,8 +63,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wa = wave >> 1, wb = wave & 1;                    // wave tile: 64 (n1) x 64 (n2)
-    const int n1_0 = blockIdx.y * 128, n2_0 = blockIdx.x * 128;
-    const int m_begin = blockIdx.z * a.rows_per_split;
+    // 1-D launch, dealt to the XCDs by launch index (g & 7): every workgroup of one row range - they share its rows of A (per n1 tile) and of
+    // B (per n2 tile) - runs on the same XCD, so the range crosses the fabric once (with (n2, n1, range) grid order the four n2 tiles of
+    // a dY slice sat on four XCDs and each k-step waited for HBM: 3.5 us per step).  Range = 8 * (slot / tiles) + XCD, tile = slot % tiles.
+    const int g_ = blockIdx.x, slot_ = g_ >> 3, ntile = a.t1 * a.t2;
+    const int tile_ = slot_ % ntile, split_ = (slot_ / ntile) * 8 + (g_ & 7);
+    const int bx = tile_ % a.t2, by = tile_ / a.t2;
+    const int n1_0 = by * 128, n2_0 = bx * 128;
+    const int m_begin = split_ * a.rows_per_split;
     int m_end = m_begin + a.rows_per_split;
     if (m_end > a.M) m_end = a.M;
     const int nsteps = (m_end - m_begin + 63) / 64;
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
     f32x4 csum[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) csum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool want_cs = a.colsum != nullptr && blockIdx.x == 0 && wb == 0;
+    const bool want_cs = a.colsum != nullptr && bx == 0 && wb == 0;
     const int n1_w = NARROW ? 0 : 64 * wa;                      // first n1 column of this wave inside the tile
     bf16x8 ones;
 #pragma unroll
@@ -360,20 +367,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_line_kernel(WgradLineArgs a) {
 
 static int tn_launch(GemmTnArgs a, bool conv, hipStream_t st) {
     const int t1 = cdiv(a.N1, 128), t2 = cdiv(a.N2, 128);
-    // split the m range until ~1024 workgroups run, but keep at least 256 rows (4 k-steps) per split
+    // row ranges: a multiple of 8 (one per XCD), ~1024 workgroups, at least 256 rows (4 k-steps) per range
     int splits = cdiv(1024, t1 * t2);
     const int max_splits = cdiv(a.M, 256);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     const int rows = (int)round_up(cdiv(a.M, splits), 64);
-    splits = cdiv(a.M, rows);
-    RALD_CHECK(splits <= 65535, "gemm_tn: too many splits");
-    a.rows_per_split = rows;
+    splits = (int)round_up(cdiv(a.M, rows), 8);                  // (ranges past the last row return at once)
+    RALD_CHECK((int64_t)t1 * t2 * splits < ((int64_t)1 << 31), "gemm_tn: grid too large");
+    a.rows_per_split = rows; a.t1 = t1; a.t2 = t2;
+    const dim3 grid((unsigned)(t1 * t2 * splits));
     const bool narrow = a.N1 <= 64;
-    if (conv && narrow) hipLaunchKernelGGL((gemm_tn_kernel<true, true>), dim3(t2, t1, splits), dim3(256), 0, st, a);
-    else if (conv) hipLaunchKernelGGL((gemm_tn_kernel<true, false>), dim3(t2, t1, splits), dim3(256), 0, st, a);
-    else if (narrow) hipLaunchKernelGGL((gemm_tn_kernel<false, true>), dim3(t2, t1, splits), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_tn_kernel<false, false>), dim3(t2, t1, splits), dim3(256), 0, st, a);
+    if (conv && narrow) hipLaunchKernelGGL((gemm_tn_kernel<true, true>), grid, dim3(256), 0, st, a);
+    else if (conv) hipLaunchKernelGGL((gemm_tn_kernel<true, false>), grid, dim3(256), 0, st, a);
+    else if (narrow) hipLaunchKernelGGL((gemm_tn_kernel<false, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_tn_kernel<false, false>), grid, dim3(256), 0, st, a);
     RALD_HIP(hipGetLastError());
     return 0;
 }
