@@ -437,8 +437,8 @@ int Ae::decode_latents(const float* z, int B, void* ctx, hipStream_t st) {
         }
         if (d == 512 && M % 64 == 0 && small_m_fused(BM, M, cfg.heads, I, 64)) {
             // small batches: attention + per-head slice of to_out in one kernel, partials summed with the residual + the FF's PreNorm
-            RALD_TRY(attn_self_proj(x_qk, 3 * I, l.w_o, x_part, M, cfg.heads, B, st));
-            RALD_TRY(reduce_resid_ln(x_part, cfg.heads, (int64_t)BM * d, l.b_o, x_x, x_h, BM, l.ff.ng, l.ff.nb, 0, 1 << 30, 0.f, 1e-5f, st));
+            RALD_TRY(attn_self_proj(x_qk, 3 * I, l.w_o, x_part, M, cfg.heads, B, st, true));
+            RALD_TRY(reduce_resid_ln(x_part, cfg.heads, (int64_t)BM * d, l.b_o, x_x, x_h, BM, l.ff.ng, l.ff.nb, 0, 1 << 30, 0.f, 1e-5f, st, true));
         } else {
         a.O = x_o; a.ldo = I; a.strideO = (int64_t)M * I;
         a.nq = M; a.nk = M; a.k_rows = M; a.heads = cfg.heads; a.batch = B; a.scale = scale; a.q_prescaled = 1;

@@ -80,7 +80,9 @@ __device__ __forceinline__ bf16x8 acc_frag(const f32x16& x, int s, float scale) 
 // part[q][n0 + (lane & 31)] = acc (rows = queries on the registers, column on the lane) through a wave-private 4-KiB LDS patch:
 // 4 stores of 16 bytes per lane (8 whole 128-byte row segments each) instead of 16 four-byte stores - the store tail of these
 // kernels is issue-bound (~45 clocks per store instruction, guide T21)
-__device__ __forceinline__ void store_part_tile(float* part_row0, int n0, const f32x16& acc, float* patch, int lane) {
+// f16 = the slabs are fp16, scaled by 2^-6 and saturated (range +-4.2e6, 11 mantissa bits: below the bf16 rounding of the operands that
+// produced them; halves the 8 MB of slab traffic per sub-block: NFE -3 % at B = 1, -6.5 % at B = 2); part_row0 then points at halves.
+__device__ __forceinline__ void store_part_tile(float* part_row0, int n0, const f32x16& acc, float* patch, int lane, bool f16) {
     const int c = lane & 31, hf = lane >> 5;
 #pragma unroll
     for (int i = 0; i < 16; ++i) patch[((i & 3) + 8 * (i >> 2) + 4 * hf) * 32 + c] = acc[i];
@@ -88,7 +90,14 @@ __device__ __forceinline__ void store_part_tile(float* part_row0, int n0, const 
     for (int j = 0; j < 4; ++j) {
         const int row = 8 * j + (lane >> 3), ch = lane & 7;
         const float4 v = *reinterpret_cast<const float4*>(patch + row * 32 + 4 * ch);
-        *reinterpret_cast<float4*>(part_row0 + (int64_t)row * 512 + n0 + 4 * ch) = v;
+        if (f16) {
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            constexpr float SC = 0.015625f, LIM = 65504.f;
+            h4 hv;
+            hv[0] = (_Float16)fminf(fmaxf(v.x * SC, -LIM), LIM); hv[1] = (_Float16)fminf(fmaxf(v.y * SC, -LIM), LIM);
+            hv[2] = (_Float16)fminf(fmaxf(v.z * SC, -LIM), LIM); hv[3] = (_Float16)fminf(fmaxf(v.w * SC, -LIM), LIM);
+            *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(part_row0) + (int64_t)row * 512 + n0 + 4 * ch) = hv;
+        } else *reinterpret_cast<float4*>(part_row0 + (int64_t)row * 512 + n0 + 4 * ch) = v;
     }
 }
 
@@ -98,8 +107,8 @@ __device__ __forceinline__ void store_part_tile(float* part_row0, int n0, const 
 struct SelfProjArgs {
     const bf16* qkv; int64_t ld;      // [batch*NL][ld]: q (pre-scaled by scale*log2e) | k | v at column offsets 0, D, 2D
     const bf16* Wo;                   // [512][512] to_out weight, row = output column n, K-contiguous
-    float* part;                      // [heads][batch*NL][512]
-    int NL, heads, batch, D;
+    float* part;                      // [heads][batch*NL][512] fp32, or fp16 x 2^-6 when part_f16
+    int NL, heads, batch, D, part_f16;
 };
 
 // LDS: [ Q tile 4 KiB | (m, l) table 2 KiB + pad | merged O (bf16) 4 KiB | per wave: K tile 8 KiB, V tile 8 KiB ] = 140 KiB
@@ -249,7 +258,8 @@ __global__ __launch_bounds__(512) void attn_self_proj_kernel(SelfProjArgs a) {
     RALD_STAMP(0, 4);
     // ---- this head's slice of the out-projection: part[q][n] = sum_d O[q][d] Wo[n][64h + d]; wave w takes n in [64w, 64w + 64)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // my share of the to_out slice has landed (wave-private space)
-    float* prow = a.part + ((int64_t)h * a.batch * a.NL + (int64_t)b * a.NL + q0) * 512;
+    const int64_t prow_el = ((int64_t)h * a.batch * a.NL + (int64_t)b * a.NL + q0) * 512;
+    float* prow = a.part_f16 ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(a.part) + prow_el) : a.part + prow_el;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         f32x16 acc;
@@ -257,7 +267,7 @@ __global__ __launch_bounds__(512) void attn_self_proj_kernel(SelfProjArgs a) {
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], line_perm_frag(s_k, 32 * nt + r, 16 * ks, hf), acc, 0, 0, 0);
-        store_part_tile(prow, 64 * wave + 32 * nt, acc, reinterpret_cast<float*>(s_v) + nt * 1024, lane);     // (every read of the exchange is behind the barrier above)
+        store_part_tile(prow, 64 * wave + 32 * nt, acc, reinterpret_cast<float*>(s_v) + nt * 1024, lane, a.part_f16 != 0);     // (every read of the exchange is behind the barrier above)
     }
     RALD_STAMP(0, 5);
 #ifdef RALD_SMALL_STAMPS
@@ -266,13 +276,13 @@ __global__ __launch_bounds__(512) void attn_self_proj_kernel(SelfProjArgs a) {
 #endif
 }
 
-int attn_self_proj(const bf16* qkv, int64_t ld, const bf16* Wo, float* part, int NL, int heads, int batch, hipStream_t st) {
+int attn_self_proj(const bf16* qkv, int64_t ld, const bf16* Wo, float* part, int NL, int heads, int batch, hipStream_t st, bool part_f16) {
     RALD_CHECK(qkv && Wo && part && batch >= 1 && batch <= 65535, "attn_self_proj: bad arguments");
     RALD_CHECK(heads == 8 && ld >= 3 * 512 && ld % 8 == 0, "attn_self_proj: 8 heads x 64 and a fused q|k|v buffer expected");
     RALD_CHECK(NL == 512, "attn_self_proj: 512 latents (one 64-key tile per wave of an 8-wave workgroup)");
     RALD_CHECK((uintptr_t)qkv % 16 == 0 && (uintptr_t)Wo % 16 == 0 && (uintptr_t)part % 16 == 0, "attn_self_proj: 16-byte alignment");
     SelfProjArgs a;
-    a.qkv = qkv; a.ld = ld; a.Wo = Wo; a.part = part; a.NL = NL; a.heads = heads; a.batch = batch; a.D = 512;
+    a.qkv = qkv; a.ld = ld; a.Wo = Wo; a.part = part; a.NL = NL; a.heads = heads; a.batch = batch; a.D = 512; a.part_f16 = part_f16 ? 1 : 0;
     constexpr int LDS = 12288 + 8 * 16384;
     static bool attr_set = false;
     if (!attr_set) {
@@ -293,7 +303,8 @@ struct CrossProjArgs {
     const bf16* Kc; int64_t ldk, strideK;     // cached condition keys: Kc[b*strideK + key*ldk + 64h + d]
     const bf16* Vt; int64_t ldvt, strideVt;   // cached condition values, transposed: Vt[b*strideVt + (64h + d)*ldvt + key]
     const bf16* Wo;                   // [512][512] attn2.to_out weight
-    float* part;                      // [heads][M][512]
+    float* part;                      // [heads][M][512] fp32, or fp16 x 2^-6 when part_f16
+    int part_f16;
     int M, NL;                        // rows, rows per sample
     float qscale;                     // softmax scale * log2(e)
 };
@@ -421,7 +432,8 @@ __global__ __launch_bounds__(512) void xattn_q2_proj_kernel(CrossProjArgs a) {
     af[0] = acc_frag(o[0], 0, inv); af[1] = acc_frag(o[0], 1, inv); af[2] = acc_frag(o[1], 0, inv); af[3] = acc_frag(o[1], 1, inv);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my pieces of the to_out slice have landed ...
     __syncthreads();                                               // ... and everyone's; nobody reads the Q^T partials any more
-    float* prow = a.part + ((int64_t)h * a.M + m0) * 512;
+    const int64_t prow_el = ((int64_t)h * a.M + m0) * 512;
+    float* prow = a.part_f16 ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(a.part) + prow_el) : a.part + prow_el;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int n0 = wave * 64 + nt * 32;
@@ -430,13 +442,13 @@ __global__ __launch_bounds__(512) void xattn_q2_proj_kernel(CrossProjArgs a) {
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], line_perm_frag(s_a, n0 + r, 16 * ks, hf), acc, 0, 0, 0);
-        store_part_tile(prow, n0, acc, reinterpret_cast<float*>(s_c) + wave * 1024, lane);
+        store_part_tile(prow, n0, acc, reinterpret_cast<float*>(s_c) + wave * 1024, lane, a.part_f16 != 0);
     }
     RALD_STAMP(1, 6);
 }
 
 int xattn_q2_proj(const bf16* hin, const bf16* Wq, const bf16* Kc, int64_t ldk, int64_t strideK, const bf16* Vt, int64_t ldvt, int64_t strideVt,
-                  const bf16* Wo, float* part, int M, int NL, int heads, int n_keys, float qscale, hipStream_t st) {
+                  const bf16* Wo, float* part, int M, int NL, int heads, int n_keys, float qscale, hipStream_t st, bool part_f16) {
     RALD_CHECK(hin && Wq && Kc && Vt && Wo && part && M >= 32, "xattn_q2_proj: bad arguments");
     RALD_CHECK(heads == 8 && n_keys == 64, "xattn_q2_proj: 8 heads x 64 and 64 condition tokens expected");
     RALD_CHECK(M % 32 == 0 && NL % 32 == 0 && M % NL == 0, "xattn_q2_proj: rows must come in whole 32-row blocks of one sample");
@@ -444,7 +456,7 @@ int xattn_q2_proj(const bf16* hin, const bf16* Wq, const bf16* Kc, int64_t ldk, 
                (uintptr_t)hin % 16 == 0 && (uintptr_t)Wq % 16 == 0 && (uintptr_t)Wo % 16 == 0, "xattn_q2_proj: 16-byte alignment of every row");
     CrossProjArgs a;
     a.hin = hin; a.Wq = Wq; a.Kc = Kc; a.ldk = ldk; a.strideK = strideK; a.Vt = Vt; a.ldvt = ldvt; a.strideVt = strideVt; a.Wo = Wo; a.part = part;
-    a.M = M; a.NL = NL; a.qscale = qscale;
+    a.M = M; a.NL = NL; a.qscale = qscale; a.part_f16 = part_f16 ? 1 : 0;
     constexpr int LDS = 65536 + 32768 + 16384;
     static bool attr_set = false;
     if (!attr_set) {

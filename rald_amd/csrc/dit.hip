@@ -616,11 +616,11 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
             // small batches (attn_small.hip): attention + that head's slice of to_out in one kernel per (head, 32-query block),
             // the 8 per-head partials summed into the residual stream together with the next AdaLN; then to_q + the 64-key
             // radar cross-attention + to_out slice likewise.  8 launches per block instead of 12.
-            RALD_TRY(attn_self_proj(ws_qk, 3 * D, l.w_o, ws_part, NL, cfg.n_heads, B, st));
-            RALD_TRY(reduce_resid_ln(ws_part, cfg.n_heads, (int64_t)M * D, l.b_o, ws_x, ws_h, M, m2, m2 + D, gstride, NL, 1.0f, 1e-5f, st));
+            RALD_TRY(attn_self_proj(ws_qk, 3 * D, l.w_o, ws_part, NL, cfg.n_heads, B, st, true));
+            RALD_TRY(reduce_resid_ln(ws_part, cfg.n_heads, (int64_t)M * D, l.b_o, ws_x, ws_h, M, m2, m2 + D, gstride, NL, 1.0f, 1e-5f, st, true));
             RALD_TRY(xattn_q2_proj(ws_h, l.w_q2, Kc + (size_t)li * D, (int64_t)L * D, (int64_t)T * L * D, Vtc + (size_t)li * D * T, T, (int64_t)L * D * T,
-                                   l.w_o2, ws_part, M, NL, cfg.n_heads, T, qscale, st));
-            RALD_TRY(reduce_resid_ln(ws_part, cfg.n_heads, (int64_t)M * D, l.b_o2, ws_x, ws_h, M, m3, m3 + D, gstride, NL, 1.0f, 1e-5f, st));
+                                   l.w_o2, ws_part, M, NL, cfg.n_heads, T, qscale, st, true));
+            RALD_TRY(reduce_resid_ln(ws_part, cfg.n_heads, (int64_t)M * D, l.b_o2, ws_x, ws_h, M, m3, m3 + D, gstride, NL, 1.0f, 1e-5f, st, true));
         } else {
         a1.O = ws_o; a1.ldo = D; a1.strideO = (int64_t)NL * D;
         a1.nq = NL; a1.nk = NL; a1.k_rows = NL; a1.heads = cfg.n_heads; a1.batch = B; a1.scale = scale; a1.q_prescaled = 1;

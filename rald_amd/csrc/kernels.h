@@ -118,13 +118,14 @@ inline int64_t attention_split_scratch_bytes(int ksplit, int nq, int heads, int 
 
 // ---------------------------------------------------------------- attn_small.hip (<= 2048 rows: fused per-head sub-blocks)
 // part[h][row][512] = (softmax(q_h k_h^T) v_h) . Wo[:, 64h:64h+64]^T  for the fused q|k|v buffer of a self-attention
-int attn_self_proj(const bf16* qkv, int64_t ld, const bf16* Wo, float* part, int NL, int heads, int batch, hipStream_t st);
+int attn_self_proj(const bf16* qkv, int64_t ld, const bf16* Wo, float* part, int NL, int heads, int batch, hipStream_t st, bool part_f16 = false);
 // part[h][row][512] = (softmax(to_q(hin)_h Kc_h^T) Vc_h) . Wo[:, 64h:64h+64]^T against 64 cached condition tokens
 int xattn_q2_proj(const bf16* hin, const bf16* Wq, const bf16* Kc, int64_t ldk, int64_t strideK, const bf16* Vt, int64_t ldvt, int64_t strideVt,
-                  const bf16* Wo, float* part, int M, int NL, int heads, int n_keys, float qscale, hipStream_t st);
+                  const bf16* Wo, float* part, int M, int NL, int heads, int n_keys, float qscale, hipStream_t st, bool part_f16 = false);
 // x[M][512] += bias + sum_s part[s]; optionally h = LN(x) * (add_one + g) + b  (norm.hip; deterministic order)
+// (part_f16: the slabs are fp16 scaled by 2^-6, as attn_self_proj / xattn_q2_proj write them with part_f16; S = 8 only)
 int reduce_resid_ln(const float* part, int S, int64_t part_stride, const float* bias, float* x, bf16* h, int M, const float* g, const float* b,
-                    int64_t gstride, int rows_per_group, float add_one, float eps, hipStream_t st);
+                    int64_t gstride, int rows_per_group, float add_one, float eps, hipStream_t st, bool part_f16 = false);
 // row count up to which the fused small-batch sub-blocks are used (measured on MI355X, tools/sweep_nfe.py: per NFE at B = 1 / 2 / 4
 // 1.41 / 1.70 / 2.59 ms fused against 1.64 / 1.89 / 2.27 ms unfused - from 2048 rows on the plain kernels fill the chip)
 inline bool small_m_fused(int M, int NL, int heads, int D, int n_keys) { return M <= 1024 && NL == 512 && heads == 8 && D == 512 && n_keys == 64; }

@@ -69,7 +69,7 @@ int layernorm_mod(const float* x, bf16* out, int M, int D, const float* g, const
 // following LayerNorm - one launch instead of LayerNorm's own.  D = 512, one wave per row.
 // SC: the slab count when it is 4 or 8 (compile time: all 2*SC slab loads of a row are in flight together; with the runtime trip count the
 // loop waited for each slab in turn - 8 dependent L2 round trips, 5 us per launch at 512 rows), 0 = any count.
-template <int SC>
+template <int SC, bool F16 = false>
 __global__ __launch_bounds__(256) void reduce_resid_ln_kernel(const float* __restrict__ part, int S, int64_t part_stride, const float* __restrict__ bias,
                                                               float* __restrict__ x, bf16* __restrict__ h, int M, const float* __restrict__ g,
                                                               const float* __restrict__ b, int64_t gstride, int rows_per_group, float add_one, float eps) {
@@ -86,10 +86,22 @@ __global__ __launch_bounds__(256) void reduce_resid_ln_kernel(const float* __res
     }
     if constexpr (SC > 0) {
         float4 p0[SC], p1[SC];
+        if constexpr (F16) {
+            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+            h8 hp[SC];
+#pragma unroll
+            for (int s = 0; s < SC; ++s) hp[s] = *reinterpret_cast<const h8*>(reinterpret_cast<const _Float16*>(part) + s * part_stride + (int64_t)row * D + lane * 8);
+#pragma unroll
+            for (int s = 0; s < SC; ++s) {
+                p0[s] = make_float4((float)hp[s][0] * 64.f, (float)hp[s][1] * 64.f, (float)hp[s][2] * 64.f, (float)hp[s][3] * 64.f);
+                p1[s] = make_float4((float)hp[s][4] * 64.f, (float)hp[s][5] * 64.f, (float)hp[s][6] * 64.f, (float)hp[s][7] * 64.f);
+            }
+        } else {
 #pragma unroll
         for (int s = 0; s < SC; ++s) {
             const float* p = part + s * part_stride + (int64_t)row * D + lane * 8;
             p0[s] = *reinterpret_cast<const float4*>(p); p1[s] = *reinterpret_cast<const float4*>(p + 4);
+        }
         }
 #pragma unroll
         for (int s = 0; s < SC; ++s) {                                  // same order of additions as the loop below
@@ -124,7 +136,13 @@ __global__ __launch_bounds__(256) void reduce_resid_ln_kernel(const float* __res
 }
 
 int reduce_resid_ln(const float* part, int S, int64_t part_stride, const float* bias, float* x, bf16* h, int M, const float* g, const float* b,
-                    int64_t gstride, int rows_per_group, float add_one, float eps, hipStream_t st) {
+                    int64_t gstride, int rows_per_group, float add_one, float eps, hipStream_t st, bool part_f16) {
+    RALD_CHECK(!part_f16 || S == 8, "reduce_resid_ln: fp16 slabs come in eights (one per head)");
+    if (part_f16) {
+        hipLaunchKernelGGL((reduce_resid_ln_kernel<8, true>), dim3(cdiv(M, 4)), dim3(256), 0, st, part, S, part_stride, bias, x, h, M, g, b, gstride, rows_per_group, add_one, eps);
+        RALD_HIP(hipGetLastError());
+        return 0;
+    }
     RALD_CHECK(part && bias && x && S >= 1 && S <= 64 && M >= 1, "reduce_resid_ln: bad arguments");
     RALD_CHECK(!h || (g && b && rows_per_group > 0), "reduce_resid_ln: LayerNorm parameters missing");
     if (S == 8) hipLaunchKernelGGL(reduce_resid_ln_kernel<8>, dim3(cdiv(M, 4)), dim3(256), 0, st, part, S, part_stride, bias, x, h, M, g, b, gstride, rows_per_group, add_one, eps);
