@@ -587,6 +587,9 @@ static int launch_glds(const GemmArgs& a, int epi, hipStream_t st) {
         case EPI_F32:   return launch_glds_epi<BM, BN, WM, WN, NSTAGE, EPI_F32>(a, st);
         case EPI_RESID: return launch_glds_epi<BM, BN, WM, WN, NSTAGE, EPI_RESID>(a, st);
         case EPI_GEGLU: return launch_glds_epi<BM, BN, WM, WN, NSTAGE, EPI_GEGLU>(a, st);
+        case EPI_F16S:
+            if constexpr (BM == 64 && BN == 64) return launch_glds_epi<BM, BN, WM, WN, NSTAGE, EPI_F16S>(a, st);
+            else { set_error("gemm: the fp16-slab epilogue is built for the small-M 64x64 ring engine only"); return 1; }
         case EPI_SOFTMAX64:
             if constexpr ((BN / WN) % 64 == 0 && BM >= 128) return launch_glds_epi<BM, BN, WM, WN, NSTAGE, EPI_SOFTMAX64>(a, st);
             else { set_error("gemm: the softmax epilogue needs waves of 64-column groups"); return 1; }
@@ -649,6 +652,10 @@ static int gemm_nt_impl(const GemmArgs& a, int epi, hipStream_t st) {
         RALD_CHECK(a.ldc >= a.N / 2, "gemm: GEGLU ldc < N/2");
     } else {
         RALD_CHECK(a.ldc >= a.N, "gemm: ldc < N");
+    }
+    if (epi == EPI_F16S) {                                        // split-K slabs of the small-M regime (resid_splitk_ln): always the 64x64 ring
+        RALD_CHECK(!a.out8 && a.N % 8 == 0, "gemm: the fp16-slab epilogue needs N % 8 == 0");
+        return launch_glds<64, 64, 2, 2, 8>(a, epi, st);
     }
     if (epi == EPI_SOFTMAX64) {
         // whole tiles only: every wave normalises complete 64-column groups of complete rows

@@ -78,7 +78,14 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[MT][NT], const Ge
                 const float al = n < a.alpha_ncols ? a.alpha : 1.0f;
                 const float o0 = al * v[0] + b.x, o1 = al * v[1] + b.y, o2 = al * v[2] + b.z, o3 = al * v[3] + b.w;
                 if constexpr (F32OUT) *reinterpret_cast<float4*>(patch + fr * STRIDE + (16 * j + 4 * fq) * 4) = make_float4(o0, o1, o2, o3);
-                else *reinterpret_cast<bf16x4*>(patch + fr * STRIDE + (16 * j + 4 * fq) * 2) = pack4(o0, o1, o2, o3);
+                else if constexpr (EPI == EPI_F16S) {
+                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                    constexpr float SC = 0.015625f, LIM = 65504.f;
+                    h4 hv;
+                    hv[0] = (_Float16)fminf(fmaxf(o0 * SC, -LIM), LIM); hv[1] = (_Float16)fminf(fmaxf(o1 * SC, -LIM), LIM);
+                    hv[2] = (_Float16)fminf(fmaxf(o2 * SC, -LIM), LIM); hv[3] = (_Float16)fminf(fmaxf(o3 * SC, -LIM), LIM);
+                    *reinterpret_cast<h4*>(patch + fr * STRIDE + (16 * j + 4 * fq) * 2) = hv;
+                } else *reinterpret_cast<bf16x4*>(patch + fr * STRIDE + (16 * j + 4 * fq) * 2) = pack4(o0, o1, o2, o3);
             }
             }
         }

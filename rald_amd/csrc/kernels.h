@@ -9,7 +9,8 @@ namespace rald {
 
 // ---------------------------------------------------------------- gemm.hip
 enum { EPI_BF16 = 0, EPI_F32 = 1, EPI_RESID = 2, EPI_GEGLU = 3,
-       EPI_SOFTMAX64 = 4 };   // C_bf16 = softmax over every aligned group of 64 output columns of alpha*acc, in exp2 units (folded cross-attention, dit.hip)
+       EPI_SOFTMAX64 = 4,
+       EPI_F16S = 5 };        // C_fp16 = 2^-6 (alpha*acc + bias), saturating: split-K slabs for reduce_resid_ln(part_f16) (norm.hip)   // C_bf16 = softmax over every aligned group of 64 output columns of alpha*acc, in exp2 units (folded cross-attention, dit.hip)
 struct GemmArgs {
     const bf16* A; int64_t lda; int64_t strideA;   // [batch][M][K] activations (K contiguous)
     const bf16* B; int64_t ldb; int64_t strideB;   // [batch][N][K] weights     (K contiguous)

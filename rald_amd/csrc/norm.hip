@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256) void reduce_resid_ln_kernel(const float* __res
     if constexpr (SC > 0) {
         float4 p0[SC], p1[SC];
         if constexpr (F16) {
+            static_assert(SC > 0, "fp16 slabs: compile-time slab count");
             typedef _Float16 h8 __attribute__((ext_vector_type(8)));
             h8 hp[SC];
 #pragma unroll
@@ -137,9 +138,10 @@ __global__ __launch_bounds__(256) void reduce_resid_ln_kernel(const float* __res
 
 int reduce_resid_ln(const float* part, int S, int64_t part_stride, const float* bias, float* x, bf16* h, int M, const float* g, const float* b,
                     int64_t gstride, int rows_per_group, float add_one, float eps, hipStream_t st, bool part_f16) {
-    RALD_CHECK(!part_f16 || S == 8, "reduce_resid_ln: fp16 slabs come in eights (one per head)");
+    RALD_CHECK(!part_f16 || S == 8 || S == 4, "reduce_resid_ln: fp16 slabs come in eights (one per head) or fours (split-K)");
     if (part_f16) {
-        hipLaunchKernelGGL((reduce_resid_ln_kernel<8, true>), dim3(cdiv(M, 4)), dim3(256), 0, st, part, S, part_stride, bias, x, h, M, g, b, gstride, rows_per_group, add_one, eps);
+        if (S == 8) hipLaunchKernelGGL((reduce_resid_ln_kernel<8, true>), dim3(cdiv(M, 4)), dim3(256), 0, st, part, S, part_stride, bias, x, h, M, g, b, gstride, rows_per_group, add_one, eps);
+        else hipLaunchKernelGGL((reduce_resid_ln_kernel<4, true>), dim3(cdiv(M, 4)), dim3(256), 0, st, part, S, part_stride, bias, x, h, M, g, b, gstride, rows_per_group, add_one, eps);
         RALD_HIP(hipGetLastError());
         return 0;
     }
@@ -159,8 +161,10 @@ int resid_splitk_ln(const bf16* A, int64_t lda, const bf16* W, int64_t ldw, cons
     RALD_CHECK(!h || (g && b && rows_per_group > 0), "resid_splitk_ln: LayerNorm parameters missing");
     GemmArgs p = gemm_args(A, lda, W, ldw, scratch, 512, nullptr, M, 512, K / splits);
     p.batch = splits; p.strideA = K / splits; p.strideB = K / splits; p.strideC = (int64_t)M * 512;
-    RALD_TRY(gemm_nt(p, EPI_F32, st));
-    return reduce_resid_ln(scratch, splits, (int64_t)M * 512, bias, x, h, M, g, b, gstride, rows_per_group, add_one, eps, st);
+    // up to 1024 rows (64x64 ring engine) the four slabs travel as fp16 x 2^-6 like the per-head slabs of attn_small.hip: half the bytes
+    const bool f16 = splits == 4 && (int64_t)cdiv(M, 64) * 8 * splits <= 256;
+    RALD_TRY(gemm_nt(p, f16 ? EPI_F16S : EPI_F32, st));
+    return reduce_resid_ln(scratch, splits, (int64_t)M * 512, bias, x, h, M, g, b, gstride, rows_per_group, add_one, eps, st, f16);
 }
 
 // ---- proj_in: K = C (latent channels, <= 64) is far too small for MFMA and stays fp32.
