@@ -588,8 +588,8 @@ static int launch_glds(const GemmArgs& a, int epi, hipStream_t st) {
         case EPI_RESID: return launch_glds_epi<BM, BN, WM, WN, NSTAGE, EPI_RESID>(a, st);
         case EPI_GEGLU: return launch_glds_epi<BM, BN, WM, WN, NSTAGE, EPI_GEGLU>(a, st);
         case EPI_F16S:
-            if constexpr (BM == 64 && BN == 64) return launch_glds_epi<BM, BN, WM, WN, NSTAGE, EPI_F16S>(a, st);
-            else { set_error("gemm: the fp16-slab epilogue is built for the small-M 64x64 ring engine only"); return 1; }
+            if constexpr ((BM == 64 && BN == 64) || (BM == 128 && BN == 128 && NSTAGE == 2)) return launch_glds_epi<BM, BN, WM, WN, NSTAGE, EPI_F16S>(a, st);
+            else { set_error("gemm: the fp16-slab epilogue is built for the 64x64 ring and the 128x128 LDS-DMA engines"); return 1; }
         case EPI_SOFTMAX64:
             if constexpr ((BN / WN) % 64 == 0 && BM >= 128) return launch_glds_epi<BM, BN, WM, WN, NSTAGE, EPI_SOFTMAX64>(a, st);
             else { set_error("gemm: the softmax epilogue needs waves of 64-column groups"); return 1; }
@@ -653,8 +653,11 @@ static int gemm_nt_impl(const GemmArgs& a, int epi, hipStream_t st) {
     } else {
         RALD_CHECK(a.ldc >= a.N, "gemm: ldc < N");
     }
-    if (epi == EPI_F16S) {                                        // split-K slabs of the small-M regime (resid_splitk_ln): always the 64x64 ring
+    if (epi == EPI_F16S) {                                        // split-K slabs (resid_splitk_ln): the 64x64 ring or 128x128 tiles, as EPI_F32 would get
         RALD_CHECK(!a.out8 && a.N % 8 == 0, "gemm: the fp16-slab epilogue needs N % 8 == 0");
+        const int64_t w128 = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) * nbatch, w64 = (int64_t)cdiv(a.M, 64) * cdiv(a.N, 64) * nbatch;
+        RALD_CHECK(w128 >= 192 || w64 <= 256, "gemm: fp16 slabs are not built for the register-staged engine (ask gemm_f16s_ok first)");
+        if (w128 >= 192) return launch_glds<128, 128, 2, 2, 2>(a, epi, st);
         return launch_glds<64, 64, 2, 2, 8>(a, epi, st);
     }
     if (epi == EPI_SOFTMAX64) {

@@ -36,6 +36,11 @@ __device__ __forceinline__ void gemm_batch_offsets(const GemmArgs& a, int bz, in
 }
 #endif
 int gemm_nt(const GemmArgs& a, int epi, hipStream_t st);
+// EPI_F16S exists on the LDS-DMA engines only: true when gemm_nt would run this shape on one of them (else use EPI_F32)
+inline bool gemm_f16s_ok(int M, int N, int batch) {
+    const int64_t w128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * batch, w64 = (int64_t)((M + 63) / 64) * ((N + 63) / 64) * batch;
+    return w128 >= 192 || w64 <= 256;
+}
 inline GemmArgs gemm_args(const bf16* A, int64_t lda, const bf16* B, int64_t ldb, void* C, int64_t ldc,
                           const float* bias, int M, int N, int K) {
     GemmArgs g;

@@ -161,8 +161,8 @@ int resid_splitk_ln(const bf16* A, int64_t lda, const bf16* W, int64_t ldw, cons
     RALD_CHECK(!h || (g && b && rows_per_group > 0), "resid_splitk_ln: LayerNorm parameters missing");
     GemmArgs p = gemm_args(A, lda, W, ldw, scratch, 512, nullptr, M, 512, K / splits);
     p.batch = splits; p.strideA = K / splits; p.strideB = K / splits; p.strideC = (int64_t)M * 512;
-    // up to 1024 rows (64x64 ring engine) the four slabs travel as fp16 x 2^-6 like the per-head slabs of attn_small.hip: half the bytes
-    const bool f16 = splits == 4 && (int64_t)cdiv(M, 64) * 8 * splits <= 256;
+    // where an LDS-DMA engine runs the product, the four slabs travel as fp16 x 2^-6 like the per-head slabs of attn_small.hip: half the bytes
+    const bool f16 = splits == 4 && gemm_f16s_ok(M, 512, splits);
     RALD_TRY(gemm_nt(p, f16 ? EPI_F16S : EPI_F32, st));
     return reduce_resid_ln(scratch, splits, (int64_t)M * 512, bias, x, h, M, g, b, gstride, rows_per_group, add_one, eps, st, f16);
 }
