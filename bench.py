@@ -35,14 +35,15 @@ PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, c
 
 
 # variables that only a PROBE build of the library reads (rald_amd/csrc/common.h), plus the library override itself
-PROBE_ONLY_ENV = ("RALD_GEMM_ABLATE", "RALD_NT_STORE", "RALD_FUSE_LN", "RALD_ATTN_VROW", "RALD_ATTN_PRESCALED", "RALD_GEMM_IMPL", "RALD_GEMM_MID",
-                  "RALD_SPLITK_MAXM", "RALD_CONV_LINE", "RALD_GN_FUSE", "RALD_CONV_SPLITK", "RALD_LIB_OVERRIDE")
+# RALD_* variables the PRODUCT reads (Python layer); every other RALD_* name is a probe-build switch of the library (RALD_PROBE_ENV in
+# rald_amd/csrc, inert in the shipped build) or an override, and a bench line measured with one set is refused
+PRODUCT_ENV = ("RALD_DIST_BACKEND", "RALD_BENCH_LEG_TIMEOUT", "RALD_GRAPH", "RALD_GRAPH_MAX_BATCH", "RALD_QKV_DTYPE")
 
 
 def env_guard():
     """config.env for the JSON line; refuses to measure anything but the shipped library at its shipped settings."""
     env = {k: v for k, v in sorted(os.environ.items()) if k.startswith("RALD_")}
-    bad = [k for k in env if k in PROBE_ONLY_ENV]
+    bad = [k for k in env if k not in PRODUCT_ENV]
     if bad:
         print(f"[bench] refusing to run: {bad} are probe-build / override switches; a number measured with them is not the product's",
               file=sys.stderr, flush=True)
