@@ -44,6 +44,8 @@ def env_guard():
     """config.env for the JSON line; refuses to measure anything but the shipped library at its shipped settings."""
     env = {k: v for k, v in sorted(os.environ.items()) if k.startswith("RALD_")}
     bad = [k for k in env if k not in PRODUCT_ENV]
+    if env.get("RALD_QKV_DTYPE", "bf16") != "bf16":
+        bad.append("RALD_QKV_DTYPE (the headline is the bf16 path; the MXFP8 modes are measured in the extras)")
     if bad:
         print(f"[bench] refusing to run: {bad} are probe-build / override switches; a number measured with them is not the product's",
               file=sys.stderr, flush=True)
