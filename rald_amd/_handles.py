@@ -190,7 +190,7 @@ class DitHandle:
 def op_gemm_nt(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = 0,
                C_inout: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
     """A [batch?,M,K] bf16, B [batch?,N,K] bf16 -> C.  epilogue 0 bf16, 1 f32, 2 f32 accumulate into
-    C_inout, 3 GEGLU (B rows / bias pre-packed)."""
+    C_inout, 3 GEGLU (B rows / bias pre-packed), 4 softmax over aligned groups of 64 columns (exp2 units, bf16)."""
     batched = A.dim() == 3 or B.dim() == 3
     batch = (A.shape[0] if A.dim() == 3 else B.shape[0]) if batched else 1
     M, K = A.shape[-2], A.shape[-1]
@@ -202,7 +202,7 @@ def op_gemm_nt(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = 
         out = C_inout
     else:
         shape = (batch, M, nc) if batched else (M, nc)
-        out = torch.empty(shape, device=A.device, dtype=torch.bfloat16 if epilogue in (0, 3) else torch.float32)
+        out = torch.empty(shape, device=A.device, dtype=torch.bfloat16 if epilogue in (0, 3, 4) else torch.float32)
     sC = out.stride(0) if out.dim() == 3 else 0
     check(lib().rald_op_gemm_nt(C.c_void_p(_ptr(A)), A.stride(-2), sA, C.c_void_p(_ptr(B)), B.stride(-2), sB,
                                 C.c_void_p(_ptr(out)), out.stride(-2), sC,

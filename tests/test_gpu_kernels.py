@@ -71,6 +71,22 @@ def test_gemm_geglu_epilogue(H, M):
     assert rel_l2(out, ref) < 4e-3          # bf16 output rounding (2^-9 relative per element)
 
 
+@pytest.mark.parametrize("Bn,M", [(64, 512), (5, 512), (1, 256)])
+def test_gemm_softmax64_epilogue_batched(H, Bn, M):
+    """The folded cross-attention's first GEMM (dit.hip cond_fold): P = softmax over every aligned group of 64 output columns of A.B^T, in
+    exp2 units, with one B per batch entry - the 256x256 engine with whole batch entries dealt to one XCD (Bn = 64) and the 128x128 one -
+    against fp32 torch; rows of every group sum to one."""
+    g = torch.Generator("cpu").manual_seed(41)
+    A = torch.randn(Bn, M, 512, generator=g).cuda().bfloat16()
+    Bm = (torch.randn(Bn, 512, 512, generator=g) / 8).cuda().bfloat16()
+    out = H.op_gemm_nt(A, Bm, epilogue=4)
+    s = torch.einsum("bmk,bnk->bmn", A.float(), Bm.float()).view(Bn, M, 8, 64) * math.log(2.0)
+    ref = torch.softmax(s, dim=-1).view(Bn, M, 512)
+    assert out.shape == (Bn, M, 512) and out.dtype == torch.bfloat16
+    assert rel_l2(out, ref) < 6e-3                                    # bf16 output rounding
+    assert float((out.float().view(Bn, M, 8, 64).sum(-1) - 1).abs().max()) < 2e-2
+
+
 @pytest.mark.parametrize("D", [256, 512, 1024])
 def test_layernorm_plain_and_modulated(H, D):
     M = 1000
