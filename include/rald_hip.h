@@ -68,13 +68,23 @@ int rald_dit_reserve(rald_dit* h, int32_t max_batch);
  * captured library calls into a hipGraph must re-capture when the value differs from the one read after capture: the
  * graph's kernels hold pointers into those buffers. */
 int64_t rald_dit_workspace_generation(const rald_dit* h);
+/* Two-stream schedule of an NFE (rald_dit_denoise / rald_dit_sample): from `min_batch` samples up (default 128) the batch runs as
+ * two half-batches on two HIP streams - the caller's and a handle-owned one, forked from and joined back into `stream` with events,
+ * so the caller sees ordinary stream semantics.  Every CU of one launch runs the same phase at the same time (matrix loop, then the
+ * store-heavy epilogue); a second independent half-batch fills those holes.  Each half runs exactly the kernels a batch of its size
+ * runs alone: results are bit-identical to two sequential calls.  0 = never split.  Re-plans the workspace (blocking). */
+int rald_dit_set_two_stream_min_batch(rald_dit* h, int32_t min_batch);
+int32_t rald_dit_two_stream_min_batch(const rald_dit* h);
 
 /* Noise-level table: for each of the n sigmas (HOST array) computes the EDM coefficients
  * (c_in, c_skip, c_out, c_noise; :422-425), the timestep embedding (:217-219) and all
  * depth*3 AdaLayerNorm modulations (:128-129) once; rald_dit_denoise refers to rows of it. */
 int rald_dit_set_sigmas(rald_dit* h, const float* sigmas_host, int32_t n, void* stream);
 
-/* Bytes of the condition cache FOR THIS BATCH SIZE (a cache is built for, and used with, one batch size): K and V^T of the condition
+/* Bytes of the condition cache FOR THIS BATCH SIZE (a cache is built for, and used with, one batch size; it starts with a 64-byte
+ * header - magic, batch, layout flag, configuration hash - that rald_dit_denoise / rald_dit_sample check against their `batch`
+ * argument BEFORE any launch: a cache this handle has not seen (a copy) is verified once by reading the header back, which
+ * synchronises `stream` and cannot happen under graph capture): K and V^T of the condition
  * tokens for every block, and from 3 samples up (bf16 mode) also the folded forms K.to_q and to_out.V^T per sample and block
  * (1 MiB each) that turn the cross-attention sub-block into two GEMMs - not a linear function of `batch`, so always ask. */
 int64_t rald_dit_cond_cache_bytes(const rald_dit* h, int32_t batch);

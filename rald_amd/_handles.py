@@ -142,10 +142,20 @@ class DitHandle:
                 raw_F: bool = False) -> torch.Tensor:
         _need_cuda(x, "x")
         x = _f32c(x)
+        if x.dim() != 3 or x.shape[1] != self.cfg.n_latents or x.shape[2] != self.cfg.channels:
+            raise RuntimeError(f"x must be [B,{self.cfg.n_latents},{self.cfg.channels}], got {tuple(x.shape)}")
+        if cache.dtype != torch.uint8 or not cache.is_cuda or cache.numel() != lib().rald_dit_cond_cache_bytes(self._h, x.shape[0]):
+            raise RuntimeError(f"condition cache of {cache.numel()} bytes does not belong to a batch of {x.shape[0]} "
+                               f"(expected {lib().rald_dit_cond_cache_bytes(self._h, x.shape[0])} bytes): encode the condition for the same batch")
         out = torch.empty_like(x)
         check(lib().rald_dit_denoise(self._h, C.c_void_p(_ptr(x)), x.shape[0], sigma_row, int(per_sample),
                                      C.c_void_p(_ptr(cache)), C.c_void_p(_ptr(out)), int(raw_F), C.c_void_p(_stream())))
         return out
+
+    def set_two_stream_min_batch(self, min_batch: int) -> None:
+        """From `min_batch` samples up an NFE runs as two half-batches on two HIP streams (default 128; 0 = never)."""
+        self._graphs.clear()                           # the workspace is re-planned
+        check(lib().rald_dit_set_two_stream_min_batch(self._h, int(min_batch)))
 
     def profile_begin(self) -> None:
         check(lib().rald_dit_profile_begin(self._h))
@@ -170,6 +180,8 @@ class DitHandle:
         _need_cuda(latents, "latents")
         latents = _f32c(latents)
         B = latents.shape[0]
+        if cache.dtype != torch.uint8 or not cache.is_cuda or cache.numel() != lib().rald_dit_cond_cache_bytes(self._h, B):
+            raise RuntimeError(f"condition cache of {cache.numel()} bytes does not belong to a batch of {B}: encode the condition for the same batch")
         self.reserve(B)
         sched = (num_steps, float(sigma_min), float(sigma_max), float(rho))
         if sched != self._sched:                       # the sampler's sigma table is rebuilt for a new schedule
@@ -362,6 +374,9 @@ class AeHandle:
         _need_cuda(queries, "queries")
         queries = _f32c(queries)
         B, Q, _ = queries.shape
+        if ctx.dtype != torch.uint8 or not ctx.is_cuda or ctx.numel() != lib().rald_ae_ctx_bytes(self._h, B):
+            raise RuntimeError(f"decoder context of {ctx.numel()} bytes does not belong to a batch of {B}: decode_latents(z) and the queries "
+                               "must have the same batch size")
         out = torch.empty(B, Q, device=queries.device, dtype=torch.float32)
         check(lib().rald_ae_decode_queries(self._h, C.c_void_p(_ptr(ctx)), C.c_void_p(_ptr(queries)), B, Q, C.c_void_p(_ptr(out)),
                                            C.c_void_p(_stream())))

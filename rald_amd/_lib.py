@@ -44,6 +44,8 @@ SIGNATURES = {
     "rald_dit_finalize": (c_int, [c_void_p]),
     "rald_dit_reserve": (c_int, [c_void_p, c_int]),
     "rald_dit_workspace_generation": (c_i64, [c_void_p]),
+    "rald_dit_set_two_stream_min_batch": (c_int, [c_void_p, c_int]),
+    "rald_dit_two_stream_min_batch": (c_int, [c_void_p]),
     "rald_ae_workspace_generation": (c_i64, [c_void_p]),
     "rald_dit_set_sigmas": (c_int, [c_void_p, c_float_p, c_int, c_void_p]),
     "rald_dit_cond_cache_bytes": (c_i64, [c_void_p, c_int]),

@@ -61,6 +61,10 @@ struct Ae {
     int reserve_encode(int B);
     int reserve_decode(int B);
     int encode(const float* pc, int B, const float* eps, float* mean_o, float* logvar_o, float* z, float* kl, hipStream_t st);
+    // decoder context: 64-byte header (BlobRegistry, dit.h) + one record per sample
+    static constexpr uint32_t CTX_MAGIC = 0x52414358u;           // "RACX"
+    BlobRegistry ctx_registry;
+    BlobHeader ctx_header(int B) const;
     int64_t ctx_bytes(int B) const;
     int decode_latents(const float* z, int B, void* ctx, hipStream_t st);
     int decode_queries(const void* ctx, const float* q, int B, int64_t Q, float* out, hipStream_t st, int nw = 0);

@@ -384,14 +384,23 @@ int Ae::reserve_decode(int B) {
 }
 
 int64_t Ae::ctx_bytes(int B) const {
-    // per sample: fp16 coefficient image [M][64] + u [M] f32 + the image's scale (ae_decode.hip)
-    return (int64_t)B * ae_ctx_stride(cfg.num_latents);
+    // 64-byte header, then per sample: fp16 coefficient image [M][64] + u [M] f32 + the image's scale (ae_decode.hip)
+    return BLOB_HEADER_BYTES + (int64_t)B * ae_ctx_stride(cfg.num_latents);
+}
+BlobHeader Ae::ctx_header(int B) const {
+    BlobHeader hd{};
+    uint32_t h = 2166136261u;
+    for (int v : {cfg.dim, cfg.num_latents, cfg.latent_dim, cfg.depth, cfg.heads, cfg.dim_head, cfg.query_type}) { h ^= (uint32_t)v; h *= 16777619u; }
+    hd.magic = CTX_MAGIC; hd.batch = B; hd.flag = 0; hd.cfg_hash = h; hd.bytes = ctx_bytes(B);
+    return hd;
 }
 
 int Ae::decode_latents(const float* z, int B, void* ctx, hipStream_t st) {
     RALD_CHECK(finalized, "ae: weights not finalized");
     RALD_CHECK(z && ctx && B >= 1 && (uintptr_t)ctx % 16 == 0, "ae: bad arguments");
     RALD_TRY(reserve_decode(B));
+    RALD_TRY(ctx_registry.stamp(ctx, ctx_header(B), st));
+    ctx = (char*)ctx + BLOB_HEADER_BYTES;
     const int M = cfg.num_latents, L = cfg.latent_dim, BM = B * M;
     const float scale = 1.0f / sqrtf((float)cfg.dim_head);
     RALD_TRY(small_k_linear(z, w_proj, b_proj, x_x, BM, L, d, st));                     // x = proj(z)  (:410)
@@ -463,6 +472,8 @@ int Ae::decode_queries(const void* ctx, const float* q, int B, int64_t Q, float*
     RALD_CHECK(finalized, "ae: weights not finalized");
     RALD_CHECK(ctx && q && out && B >= 1 && Q >= 1, "ae: bad arguments");
     RALD_CHECK((uintptr_t)ctx % 16 == 0, "ae: decoder context must be 16-byte aligned");
+    RALD_TRY(ctx_registry.check(ctx, ctx_header(B), st, "decoder context"));
+    ctx = (const char*)ctx + BLOB_HEADER_BYTES;
     return ae_decode_stream(ctx, l_img, q, out, basis, basis_diag, B, Q, cfg.num_latents, c0, st, nw);
 }
 

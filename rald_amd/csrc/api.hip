@@ -51,6 +51,17 @@ int rald_dit_reserve(rald_dit* h, int32_t max_batch) {
     return h->impl.reserve(max_batch);
 }
 int64_t rald_dit_workspace_generation(const rald_dit* h) { return h ? h->impl.ws_generation : -1; }
+int rald_dit_set_two_stream_min_batch(rald_dit* h, int32_t min_batch) {
+    RALD_CHECK(h && min_batch >= 0, "rald_dit_set_two_stream_min_batch: bad argument");
+    h->impl.split_min = min_batch;
+    if (h->impl.ws_batch > 0) {                  // re-plan the workspace (the second half's buffers exist only when the split can happen)
+        const int B = h->impl.ws_batch;
+        h->impl.ws_batch = 0;
+        return h->impl.reserve(B);
+    }
+    return 0;
+}
+int32_t rald_dit_two_stream_min_batch(const rald_dit* h) { return h ? h->impl.split_min : -1; }
 int rald_dit_set_sigmas(rald_dit* h, const float* sigmas_host, int32_t n, void* stream) {
     RALD_CHECK(h && sigmas_host, "rald_dit_set_sigmas: null argument");
     return h->impl.set_sigmas(sigmas_host, n, (hipStream_t)stream);

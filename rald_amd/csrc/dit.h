@@ -1,5 +1,6 @@
 // Host-side state of the denoiser handle (C++; the C-ABI wrappers live in api.hip).
 #pragma once
+#include <map>
 #include <set>
 #include <string>
 #include <vector>
@@ -17,6 +18,20 @@ struct DeviceArena {
     void* alloc(size_t bytes, bool zero);
     void release(void* p);
     ~DeviceArena();
+};
+
+// Caller-owned opaque device blobs (the denoiser's condition cache, the autoencoder's decoder context) have a layout that depends
+// on the batch they were built for.  Each starts with a 64-byte header (magic, batch, layout flag, configuration hash, size),
+// mirrored in a host-side registry keyed by the device pointer.  A call that consumes a blob checks the registry BEFORE any launch;
+// an unknown pointer (a copy of a blob, a recycled address) is verified once by reading its header back (synchronises the stream;
+// impossible under graph capture, where the call fails instead).
+struct BlobHeader { uint32_t magic; int32_t batch; int32_t flag; uint32_t cfg_hash; int64_t bytes; uint32_t pad[10]; };
+static_assert(sizeof(BlobHeader) == 64, "blob header is 64 bytes");
+constexpr int BLOB_HEADER_BYTES = 64;
+struct BlobRegistry {
+    std::map<const void*, BlobHeader> known;
+    int stamp(void* blob, const BlobHeader& hd, hipStream_t st);                                  // writes the header (a kernel on st) and registers it
+    int check(const void* blob, const BlobHeader& want, hipStream_t st, const char* what);       // 0 when blob carries exactly `want`
 };
 
 // fp32 host/device tensor -> packed device tensor (blocking; setup time only)
@@ -88,11 +103,36 @@ struct Dit {
     // at (workspace, sigma tables): owners of captured graphs compare it with the value at capture time.
     int64_t ws_generation = 0;
     int ws_batch = 0;
-    float* ws_part = nullptr;   // split-K partial sums of the small-batch FF2 (norm.hip resid_splitk_ln)
-    float *ws_x = nullptr, *ws_xcur = nullptr, *ws_xeul = nullptr, *ws_den = nullptr, *ws_dcur = nullptr;
-    unsigned char *ws_h8 = nullptr, *ws_hs = nullptr;   // MXFP8 AdaLN outputs feeding q/k/v (qkv_dtype >= 1)
-    unsigned char *ws_g8 = nullptr, *ws_gs = nullptr;   // MXFP8 GEGLU output feeding ff.net.2 (qkv_dtype == 3)
-    bf16 *ws_h = nullptr, *ws_qk = nullptr, *ws_vt = nullptr, *ws_o = nullptr, *ws_q2 = nullptr, *ws_g = nullptr, *ws_tok = nullptr;
+    // the per-NFE activations of one batch (or of one half of a batch, see two-stream schedule below)
+    struct Work {
+        float* x = nullptr;                 // residual stream [M][D] fp32
+        float* part = nullptr;              // split-K partial sums of the small-batch FF2 (norm.hip resid_splitk_ln) / per-head slabs
+        bf16 *h = nullptr, *qk = nullptr, *vt = nullptr, *o = nullptr, *q2 = nullptr, *g = nullptr;
+        unsigned char *h8 = nullptr, *hs = nullptr;   // MXFP8 AdaLN outputs feeding q/k/v (qkv_dtype >= 1)
+        unsigned char *g8 = nullptr, *gs = nullptr;   // MXFP8 GEGLU output feeding ff.net.2 (qkv_dtype == 3)
+        int rows = 0;
+    };
+    Work wk[2];                             // wk[0]: the whole batch (or its first half), wk[1]: the second half on the side stream
+    int alloc_work(Work& w, size_t M);
+    void free_work(Work& w);
+    float *ws_xcur = nullptr, *ws_xeul = nullptr, *ws_den = nullptr, *ws_dcur = nullptr;
+    bf16* ws_tok = nullptr;
+    // Two-stream schedule: from `split_min` samples up an NFE runs as two half-batches on two HIP streams (the caller's and a
+    // handle-owned one, fork / join by events).  Inside one launch every CU runs the same phase at the same time (MFMA loop,
+    // then the store-heavy epilogue; an HBM-bound kernel leaves the matrix cores idle): a second, independent half-batch fills
+    // those holes.  Each half runs exactly the kernels a batch of that size runs alone, so results are bit-identical to two
+    // sequential calls.  split_min = 0 turns it off.
+    int split_min = 128;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool fork_pending = false;
+    int split_sizes(int B, int& b0) const { b0 = ((B / 2 + 7) / 8) * 8; return split_min > 0 && B >= split_min && b0 < B; }
+    // condition cache header + registry (BlobRegistry above)
+    static constexpr uint32_t COND_MAGIC = 0x52414c44u;          // "RALD"
+    static constexpr int COND_HEADER_BYTES = BLOB_HEADER_BYTES;
+    BlobRegistry cond_registry;
+    uint32_t cfg_hash() const;
+    BlobHeader cond_header(int B) const;
 
     // live timing of the dominant kernel (the FF1 GEGLU GEMM) with HIP events on the launch stream
     bool prof_on = false;
@@ -116,6 +156,9 @@ struct Dit {
     int encode_cond_tokens(const float* tokens, int B, void* cache, hipStream_t st);
     int encode_cond(const float* cube, int B, float* out_tokens, void* cache, hipStream_t st);
     int denoise(const float* x, int B, int sigma_row, int per_sample, const void* cache, float* out, int raw_F, hipStream_t st, int slot = 0);
+    // samples [b0, b0 + Bn) of a batch of Bfull (the condition cache is laid out for Bfull) on workspace w
+    int denoise_range(const float* x, int Bfull, int b0, int Bn, int sigma_row, int per_sample, const void* cache, float* out, int raw_F,
+                      hipStream_t st, int slot, Work& w, bool timed_ok);
     int sample(const float* latents, int B, const void* cache, int num_steps, float smin, float smax, float rho, float* out,
                hipStream_t st);
 };

@@ -266,49 +266,70 @@ int Dit::finalize() {
     return 0;
 }
 
-int Dit::reserve(int B) {
-    if (B <= ws_batch) return 0;
-    RALD_HIP(hipDeviceSynchronize());
-    ++ws_generation;
-    for (void* p : {(void*)ws_h8, (void*)ws_hs, (void*)ws_g8, (void*)ws_gs, (void*)ws_part})
+void Dit::free_work(Work& w) {
+    for (void* p : {(void*)w.x, (void*)w.part, (void*)w.h, (void*)w.qk, (void*)w.vt, (void*)w.o, (void*)w.q2, (void*)w.g, (void*)w.h8, (void*)w.hs,
+                    (void*)w.g8, (void*)w.gs})
         if (p) arena.release(p);
-    for (void* p : {(void*)ws_x, (void*)ws_h, (void*)ws_qk, (void*)ws_vt, (void*)ws_o, (void*)ws_q2, (void*)ws_g, (void*)ws_tok,
-                    (void*)ws_xcur, (void*)ws_xeul, (void*)ws_den, (void*)ws_dcur})
-        if (p) arena.release(p);
-    const size_t M = (size_t)B * cfg.n_latents;
-    const size_t nl = (size_t)B * cfg.n_latents * cfg.channels;
-    ws_x = (float*)arena.alloc(M * D * 4, true);
-    ws_h = (bf16*)arena.alloc(M * D * 2, true);
-    ws_qk = (bf16*)arena.alloc(M * 3 * D * 2, true);       // q | k | v rows of 3*D
-    ws_vt = (bf16*)arena.alloc((size_t)B * D * cfg.n_latents * 2, true);
-    ws_o = (bf16*)arena.alloc(M * D * 2, true);
-    ws_q2 = (bf16*)arena.alloc(M * D * 2, true);
-    ws_g = (bf16*)arena.alloc(M * 4 * D * 2, true);
+    w = Work();
+}
+int Dit::alloc_work(Work& w, size_t M) {
+    const size_t B = M / cfg.n_latents;
+    w.x = (float*)arena.alloc(M * D * 4, true);
+    w.h = (bf16*)arena.alloc(M * D * 2, true);
+    w.qk = (bf16*)arena.alloc(M * 3 * D * 2, true);       // q | k | v rows of 3*D
+    w.vt = (bf16*)arena.alloc(B * D * cfg.n_latents * 2, true);
+    w.o = (bf16*)arena.alloc(M * D * 2, true);
+    w.q2 = (bf16*)arena.alloc(M * D * 2, true);
+    w.g = (bf16*)arena.alloc(M * 4 * D * 2, true);
     // split-K partials of the small-batch FF2 (4 slabs of up to splitk_max_rows() rows) / per-head partials of the fused
     // attention sub-blocks (n_heads slabs of up to 2048 rows, kernels.h small_m_fused)
     {
         const size_t r4 = M < (size_t)splitk_max_rows() ? M : (size_t)splitk_max_rows();
         const size_t r8 = M < 2048 ? M : 2048;
         const size_t slabs_rows = 4 * r4 > (size_t)cfg.n_heads * r8 ? 4 * r4 : (size_t)cfg.n_heads * r8;
-        ws_part = (float*)arena.alloc(slabs_rows * 512 * 4, true);
+        w.part = (float*)arena.alloc(slabs_rows * 512 * 4, true);
+    }
+    RALD_CHECK(w.x && w.h && w.qk && w.vt && w.o && w.q2 && w.g && w.part, "dit: workspace allocation failed");
+    if (cfg.qkv_dtype >= 1) {
+        w.h8 = (unsigned char*)arena.alloc(M * D, true);
+        w.hs = (unsigned char*)arena.alloc(M * D / 32, true);
+        RALD_CHECK(w.h8 && w.hs, "dit: workspace allocation failed");
+        if (cfg.qkv_dtype == 3) {
+            w.g8 = (unsigned char*)arena.alloc(M * 4 * D, true);
+            w.gs = (unsigned char*)arena.alloc(M * 4 * D / 32, true);
+            RALD_CHECK(w.g8 && w.gs, "dit: workspace allocation failed");
+        }
+    }
+    w.rows = (int)M;
+    return 0;
+}
+
+int Dit::reserve(int B) {
+    if (B <= ws_batch) return 0;
+    RALD_HIP(hipDeviceSynchronize());
+    ++ws_generation;
+    free_work(wk[0]);
+    free_work(wk[1]);
+    for (void* p : {(void*)ws_tok, (void*)ws_xcur, (void*)ws_xeul, (void*)ws_den, (void*)ws_dcur})
+        if (p) arena.release(p);
+    const size_t M = (size_t)B * cfg.n_latents;
+    const size_t nl = (size_t)B * cfg.n_latents * cfg.channels;
+    RALD_TRY(alloc_work(wk[0], M));
+    int b0 = 0;
+    if (split_sizes(B, b0)) {                                   // the second half of a two-stream NFE works on buffers of its own
+        RALD_TRY(alloc_work(wk[1], (size_t)b0 * cfg.n_latents));
+        if (!side) {
+            RALD_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            RALD_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+            RALD_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        }
     }
     ws_tok = (bf16*)arena.alloc((size_t)B * cfg.n_cond_tokens * cfg.context_dim * 2, true);
     ws_xcur = (float*)arena.alloc(nl * 4, true);
     ws_xeul = (float*)arena.alloc(nl * 4, true);
     ws_den = (float*)arena.alloc(nl * 4, true);
     ws_dcur = (float*)arena.alloc(nl * 4, true);
-    RALD_CHECK(ws_x && ws_h && ws_qk && ws_vt && ws_o && ws_q2 && ws_g && ws_tok && ws_xcur && ws_xeul && ws_den && ws_dcur,
-               "dit: workspace allocation failed");
-    if (cfg.qkv_dtype >= 1) {
-        ws_h8 = (unsigned char*)arena.alloc(M * D, true);
-        ws_hs = (unsigned char*)arena.alloc(M * D / 32, true);
-        RALD_CHECK(ws_h8 && ws_hs, "dit: workspace allocation failed");
-        if (cfg.qkv_dtype == 3) {
-            ws_g8 = (unsigned char*)arena.alloc(M * 4 * D, true);
-            ws_gs = (unsigned char*)arena.alloc(M * 4 * D / 32, true);
-            RALD_CHECK(ws_g8 && ws_gs, "dit: workspace allocation failed");
-        }
-    }
+    RALD_CHECK(ws_tok && ws_xcur && ws_xeul && ws_den && ws_dcur, "dit: workspace allocation failed");
     ws_batch = B;
     return 0;
 }
@@ -372,9 +393,62 @@ bool Dit::cond_fold(int B) const {
 }
 
 int64_t Dit::cond_cache_bytes(int B) const {
-    // Kc [B*T][L*D] bf16  +  Vtc [B][L*D][T] bf16;  with cond_fold also Vc [B*T][L*D], Gt [B][L][D][D], Ut [B][L][D][D]
+    // 64-byte header, then Kc [B*T][L*D] bf16  +  Vtc [B][L*D][T] bf16;  with cond_fold also Vc [B*T][L*D], Gt [B][L][D][D], Ut [B][L][D][D]
     const int64_t kv = (int64_t)B * cfg.n_cond_tokens * cfg.depth * D * 2;
-    return cond_fold(B) ? 3 * kv + (int64_t)2 * B * cfg.depth * D * D * 2 : 2 * kv;
+    return COND_HEADER_BYTES + (cond_fold(B) ? 3 * kv + (int64_t)2 * B * cfg.depth * D * D * 2 : 2 * kv);
+}
+
+uint32_t Dit::cfg_hash() const {
+    uint32_t h = 2166136261u;
+    for (int v : {cfg.n_latents, cfg.channels, cfg.depth, cfg.n_heads, cfg.d_head, cfg.context_dim, cfg.n_cond_tokens, cfg.qkv_dtype}) {
+        h ^= (uint32_t)v; h *= 16777619u;
+    }
+    return h;
+}
+
+// writes the header with a kernel (a host struct handed to an async copy would have to outlive the call)
+__global__ void blob_header_kernel(uint32_t* dst, uint32_t magic, int batch, int flag, uint32_t hash, int64_t bytes) {
+    if (threadIdx.x == 0) {
+        dst[0] = magic; dst[1] = (uint32_t)batch; dst[2] = (uint32_t)flag; dst[3] = hash;
+        dst[4] = (uint32_t)(bytes & 0xffffffffu); dst[5] = (uint32_t)((uint64_t)bytes >> 32);
+        for (int i = 6; i < 16; ++i) dst[i] = 0;
+    }
+}
+int BlobRegistry::stamp(void* blob, const BlobHeader& hd, hipStream_t st) {
+    RALD_CHECK(blob && (uintptr_t)blob % 16 == 0, "blob must be a 16-byte aligned device pointer");
+    hipLaunchKernelGGL(blob_header_kernel, dim3(1), dim3(64), 0, st, (uint32_t*)blob, hd.magic, hd.batch, hd.flag, hd.cfg_hash, hd.bytes);
+    RALD_HIP(hipGetLastError());
+    if (known.size() > 4096) known.clear();                    // bounded: entries of freed blobs are only ever replaced
+    known[blob] = hd;
+    return 0;
+}
+int BlobRegistry::check(const void* blob, const BlobHeader& want, hipStream_t st, const char* what) {
+    const std::string w(what);
+    RALD_CHECK(blob && (uintptr_t)blob % 16 == 0, w + " must be a 16-byte aligned device pointer");
+    auto same = [&](const BlobHeader& h) {
+        return h.magic == want.magic && h.batch == want.batch && h.flag == want.flag && h.cfg_hash == want.cfg_hash && h.bytes == want.bytes;
+    };
+    auto it = known.find(blob);
+    if (it != known.end() && same(it->second)) return 0;
+    // unknown pointer (a copy, a recycled address) or a registered blob of another batch: the header in device memory decides
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cs);
+    RALD_CHECK(cs == hipStreamCaptureStatusNone, w + " is not known to this handle for this batch size; use it once outside graph capture first");
+    BlobHeader hd;
+    RALD_HIP(hipStreamSynchronize(st));            // the header may still be in flight on this stream (a copy enqueued by the caller)
+    RALD_HIP(hipMemcpy(&hd, blob, sizeof(hd), hipMemcpyDeviceToHost));
+    RALD_CHECK(hd.magic == want.magic, w + ": no header found (not produced by this library's encode / decode_latents call)");
+    RALD_CHECK(hd.cfg_hash == want.cfg_hash, w + " was built by a handle with another configuration");
+    RALD_CHECK(hd.batch == want.batch, w + " was built for batch " + std::to_string(hd.batch) + ", used with batch " + std::to_string(want.batch));
+    RALD_CHECK(hd.flag == want.flag && hd.bytes == want.bytes, w + ": layout does not match this batch size");
+    known[blob] = hd;
+    return 0;
+}
+
+BlobHeader Dit::cond_header(int B) const {
+    BlobHeader hd{};
+    hd.magic = COND_MAGIC; hd.batch = B; hd.flag = cond_fold(B) ? 1 : 0; hd.cfg_hash = cfg_hash(); hd.bytes = cond_cache_bytes(B);
+    return hd;
 }
 
 int Dit::encode_cond_tokens(const float* tokens, int B, void* cache, hipStream_t st) {
@@ -383,8 +457,9 @@ int Dit::encode_cond_tokens(const float* tokens, int B, void* cache, hipStream_t
     RALD_CHECK((uintptr_t)cache % 16 == 0, "dit: cond cache must be 16-byte aligned");
     RALD_TRY(reserve(B));
     const int T = cfg.n_cond_tokens, Cd = cfg.context_dim, L = cfg.depth;
+    RALD_TRY(cond_registry.stamp(cache, cond_header(B), st));
     RALD_TRY(cast_f32_bf16(tokens, ws_tok, (int64_t)B * T * Cd, st));
-    bf16* Kc = (bf16*)cache;
+    bf16* Kc = (bf16*)((char*)cache + COND_HEADER_BYTES);
     bf16* Vtc = Kc + (size_t)B * T * L * D;
     // K for all blocks at once: [B*T, Cd] x [L*D, Cd]^T
     GemmArgs g = gemm_args(ws_tok, Cd, w_k2_all, Cd, Kc, (int64_t)L * D, nullptr, B * T, L * D, Cd);
@@ -435,16 +510,49 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
     const SigmaTable& tb = tables[slot];
     RALD_CHECK(!tb.key.empty(), "dit: rald_dit_set_sigmas has not been called");
     RALD_CHECK(sigma_row >= 0 && sigma_row + (per_sample ? B : 1) <= tb.n, "dit: sigma_row out of range of the sigma table");
+    RALD_TRY(cond_registry.check(cache, cond_header(B), st, "condition cache"));
     RALD_TRY(reserve(B));
+    int b0 = 0;
+    if (split_sizes(B, b0) && wk[1].rows >= b0 * cfg.n_latents && side) {
+        // two half-batches on two streams: fork from the caller's stream, join back into it
+        // The second half starts when the first one reaches its first feed-forward (about half a block later): launched together the
+        // two halves would run the same kernel at the same time and compete for the same unit; half a block apart the matrix-bound
+        // feed-forward GEMMs of one half meet the attention / residual + LayerNorm kernels of the other (measured: no gain without
+        // the offset).
+        fork_pending = true;
+        RALD_TRY(denoise_range(x, B, 0, b0, sigma_row, per_sample, cache, out, raw_F, st, slot, wk[0], true));
+        if (fork_pending) { RALD_HIP(hipEventRecord(ev_fork, st)); fork_pending = false; }      // (depth-0 models never reach the mark)
+        RALD_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+        RALD_TRY(denoise_range(x, B, b0, B - b0, sigma_row, per_sample, cache, out, raw_F, side, slot, wk[1], false));
+        RALD_HIP(hipEventRecord(ev_join, side));
+        RALD_HIP(hipStreamWaitEvent(st, ev_join, 0));
+        return 0;
+    }
+    return denoise_range(x, B, 0, B, sigma_row, per_sample, cache, out, raw_F, st, slot, wk[0], true);
+}
+
+int Dit::denoise_range(const float* x, int Bfull, int b0, int B, int sigma_row, int per_sample, const void* cache, float* out, int raw_F,
+                       hipStream_t st, int slot, Work& w, bool timed_ok) {
+    const SigmaTable& tb = tables[slot];
     const int NL = cfg.n_latents, T = cfg.n_cond_tokens, L = cfg.depth, C = cfg.channels;
     const int M = B * NL;
+    RALD_CHECK(w.rows >= M, "dit: workspace smaller than the batch (internal)");
+    float* const ws_x = w.x; float* const ws_part = w.part;
+    bf16 *const ws_h = w.h, *const ws_qk = w.qk, *const ws_vt = w.vt, *const ws_o = w.o, *const ws_q2 = w.q2, *const ws_g = w.g;
+    unsigned char *const ws_h8 = w.h8, *const ws_hs = w.hs, *const ws_g8 = w.g8, *const ws_gs = w.gs;
+    x += (size_t)b0 * NL * C;
+    out += (size_t)b0 * NL * C;
     const int64_t mrow = mod_row();
-    const float* mod = tb.mod + (int64_t)sigma_row * mrow;
+    const int srow = sigma_row + (per_sample ? b0 : 0);
+    const float* mod = tb.mod + (int64_t)srow * mrow;
     const int64_t gstride = per_sample ? mrow : 0;
-    const float* coef = raw_F ? coef_raw : tb.coef + 4 * (int64_t)sigma_row;
+    const float* coef = raw_F ? coef_raw : tb.coef + 4 * (int64_t)srow;
     const int cstride = (per_sample && !raw_F) ? 4 : 0;
-    const bf16* Kc = (const bf16*)cache;
-    const bf16* Vtc = Kc + (size_t)B * T * L * D;
+    // the cache is laid out for the FULL batch; this range's rows start at sample b0
+    const bf16* Kc0 = (const bf16*)((const char*)cache + COND_HEADER_BYTES);
+    const bf16* Vtc0 = Kc0 + (size_t)Bfull * T * L * D;
+    const bf16* Kc = Kc0 + (size_t)b0 * T * L * D;
+    const bf16* Vtc = Vtc0 + (size_t)b0 * L * D * T;
     const float scale = 1.0f / sqrtf((float)cfg.d_head);
     const float qscale = scale * 1.4426950408889634f;     // softmax scale and log2(e) folded into q by the projection epilogue
 
@@ -482,9 +590,11 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
         if (mnext) RALD_TRY(layernorm_mod(ws_x, ws_h, M, D, mnext, mnext + D, gstride, NL, 1.0f, 1e-5f, st));
         return 0;
     };
-    const bool fold = cond_fold(B);
-    const bf16* Gt = Vtc + (size_t)2 * B * T * L * D;               // (behind Vc; only there when fold)
-    const bf16* Ut = Gt + (size_t)B * L * D * D;
+    const bool fold = cond_fold(Bfull);
+    RALD_CHECK(!fold || !small_m_fused(M, NL, cfg.n_heads, D, T), "dit: a folded condition cache cannot feed the small-batch kernels (internal)");
+    const bf16* Gt0 = Vtc0 + (size_t)2 * Bfull * T * L * D;         // (behind Vc; only there when fold)
+    const bf16* Gt = Gt0 + (size_t)b0 * L * D * D;
+    const bf16* Ut = Gt0 + (size_t)Bfull * L * D * D + (size_t)b0 * L * D * D;
     RALD_TRY(proj_in(x, w_in, ws_x, M, C, D, coef, cstride, NL, st));
     if (cfg.qkv_dtype >= 1) {
         // ---- MXFP8 q/k/v projections (BASELINE config #5; qkv_dtype 2 adds the GEGLU projection of the feed-forward).  The AdaLN outputs that feed to_q / to_k / to_v (norm1,
@@ -553,6 +663,7 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
             a2.nq = NL; a2.nk = T; a2.k_rows = T; a2.heads = cfg.n_heads; a2.batch = B; a2.scale = scale; a2.q_prescaled = 1;
             RALD_TRY(attention_d64(a2, st));
             // qkv_dtype 3: the GEGLU output leaves the FF1 epilogue as MXFP8 and ff.net.2 (+ residual + next AdaLN) consumes it
+            if (fork_pending && timed_ok) { RALD_HIP(hipEventRecord(ev_fork, st)); fork_pending = false; }   // two-stream schedule: the other half starts here
             const bool ff2_mx = cfg.qkv_dtype == 3 && M % 256 == 0 && M >= 4096 && fuse_ln && gemm_resid_ln_pays(M, 4 * D);
             if (cfg.qkv_dtype >= 2) {
                 RALD_TRY(resid_ln8(ws_o, D, l.w_o2, D, l.b_o2, D, m3));                  // + norm3 (MXFP8)
@@ -648,8 +759,9 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
         }
         }
         // ---- x += ff(norm3(x, t))                                                   (:168)
+        if (fork_pending && timed_ok) { RALD_HIP(hipEventRecord(ev_fork, st)); fork_pending = false; }   // two-stream schedule: the other half starts here
         GemmArgs f1 = gemm_args(ws_h, D, l.w_ff1, D, ws_g, 4 * D, l.b_ff1, M, 8 * D, D);
-        const bool timed = prof_on && prof_used + 2 <= (int)prof_ev.size();
+        const bool timed = timed_ok && prof_on && prof_used + 2 <= (int)prof_ev.size();
         if (timed) RALD_HIP(hipEventRecord(prof_ev[prof_used], st));
         RALD_TRY(gemm_nt(f1, EPI_GEGLU, st));
         if (timed) { RALD_HIP(hipEventRecord(prof_ev[prof_used + 1], st)); prof_used += 2; }
@@ -685,11 +797,15 @@ int Dit::profile_end(double* total_ms, int* launches) {
 }
 Dit::~Dit() {
     for (auto& e : prof_ev) (void)hipEventDestroy(e);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (side) (void)hipStreamDestroy(side);
 }
 
 int Dit::sample(const float* latents, int B, const void* cache, int num_steps, float smin, float smax, float rho,
                 float* out, hipStream_t st) {
     RALD_CHECK(num_steps >= 2 && num_steps <= 2048, "dit: num_steps must be in [2,2048]");
+    RALD_TRY(cond_registry.check(cache, cond_header(B), st, "condition cache"));
     // Karras schedule in fp32, as the reference computes it (edm_sampler :246-249); t_N = 0.
     std::vector<float> t(num_steps + 1);
     const float a = powf(smax, 1.0f / rho), b = powf(smin, 1.0f / rho);

@@ -25,6 +25,7 @@
 //              packed rows [32t,32t+16) are the 'x' half and [32t+16,32t+32) the 'gate' half of
 //              output columns [16t,16t+16)  (models_radar_generation.py:93-95, models_ae.py:52-54)
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
@@ -196,6 +197,12 @@ typedef const __attribute__((address_space(1))) void glb_void;
 #ifdef RALD_GEMM_CLOCK   // tools/probe/gemm_clock.hip: shader clocks vs the 100 MHz wall clock over one workgroup's life
 __device__ long long g_gemm_clk[2];
 #endif
+#ifdef RALD_GEMM_STAMPS  // tools/probe/gemm_timeline.hip: per-workgroup wall-clock stamps (100 MHz) + hardware ids, one record per launch-order block
+__device__ long long g_gemm_stamps[8192][8];
+#define RALD_GSTAMP(i) do { if (threadIdx.x == 0) g_gemm_stamps[lin & 8191][i] = wall_clock64(); } while (0)
+#else
+#define RALD_GSTAMP(i) do { } while (0)
+#endif
 template <int BM, int BN, int WM, int WN, int NSTAGE, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_glds_kernel(GemmArgs a) {
 #ifdef RALD_GEMM_CLOCK
@@ -225,7 +232,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_glds_kernel(GemmArgs a) 
     const int lin = blockIdx.y * gridDim.x + blockIdx.x;
     const int xcd = lin & 7, q = nt >> 3, rr = nt & 7;
     const int tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (lin >> 3);
-    constexpr int GN = 8;
+    RALD_GSTAMP(0);
+#ifdef RALD_GEMM_STAMPS
+    if (threadIdx.x == 0) { g_gemm_stamps[lin & 8191][6] = __builtin_amdgcn_s_getreg(63492); g_gemm_stamps[lin & 8191][7] = __builtin_amdgcn_s_getreg(63508); }
+#endif
+    const int GN = RALD_ABLATED(a.ablate, 128) ? 16 : 8;       // probe builds: bit 128 = strips of 16 n-tiles (A panels fetched once at N = 4096)
     int tm, tn;
     if (ntn % GN == 0) {
         const int strip = tile / (ntm * GN), within = tile % (ntm * GN);
@@ -314,35 +325,75 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_glds_kernel(GemmArgs a) 
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     };
     if constexpr (NSTAGE == 2) {
-        // Software-pipelined main loop: the fragment registers are double-buffered so that the LDS reads
-        // of the NEXT 32-deep sub-step are in flight while the MFMAs of the current one issue (the
-        // compiler's own schedule was read-burst -> lgkmcnt(0) -> MFMA-burst, four exposed LDS
-        // latencies per tile).  The tile hand-over (DMA wait + barrier + next DMA) sits between the two
-        // MFMA bursts of an iteration, so neither burst waits on LDS.
+        // Software-pipelined main loop, rotated so that an iteration starts right AFTER a tile hand-over (barrier): nothing is
+        // pending on the LDS counter at the loop head, so the compiler's waits inside the iteration are exact counts (round 2: the
+        // loop head carried pending fragment reads and hipcc answered with lgkmcnt(0) in front of every first MFMA burst, i.e. the
+        // 12 reads just issued were waited for before any MFMA could go - a third of a k-step with the matrix pipe idle).
+        // The fragment registers are double-buffered: F0 = 32-deep sub-step 0 of a tile, F1 = sub-step 1.  An iteration:
+        //   DMA of tile kt+1 into the buffer that tile kt-1 has just left | reads F0(kt) under the MFMAs of F1(kt-1) |
+        //   reads F1(kt) under the MFMAs of F0(kt) | wait (tile kt+1 landed, my reads of tile kt done) + barrier.
+        // The DMA issues and the LDS reads are spread between the MFMAs (sched_group_barrier) instead of in front of them.
         bf16x8 fa0[MT], fb0[NT], fa1[MT], fb1[NT];
+        constexpr int W_ALL = 0x0070;                                                  // vmcnt(0) lgkmcnt(0), expcnt untouched
+        constexpr int W_ST1 = ((CA + CB) & 15) | (((CA + CB) >> 4) << 14) | 0x0f70;    // vmcnt(CA+CB): the older stage has landed
         stage(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (nk > 1 && !RALD_ABLATED(a.ablate, 1)) { stage(1, 1); __builtin_amdgcn_s_waitcnt(W_ST1); }
+        else __builtin_amdgcn_s_waitcnt(W_ALL);
         __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (nk > 1 && !RALD_ABLATED(a.ablate, 1)) stage(1, 1);
+        RALD_GSTAMP(1);
         read_frags(0, 0, fa0, fb0);
-        for (int kt = 0; kt < nk; ++kt) {
+        read_frags(0, 1, fa1, fb1);
+        mfma_all(fa0, fb0);
+        __builtin_amdgcn_s_waitcnt(W_ALL);
+        __builtin_amdgcn_s_barrier();
+        auto body = [&](int kt, auto with_dma) {
             const int cur = kt & 1;
-            read_frags(cur, 1, fa1, fb1);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_all(fa0, fb0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt + 1 < nk) {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tile kt+1 landed; my reads of tile kt are done
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                if (kt + 2 < nk && !RALD_ABLATED(a.ablate, 1)) stage(kt + 2, cur);      // buffer `cur` is free now
-                read_frags(cur ^ 1, 0, fa0, fb0);
-                __builtin_amdgcn_sched_barrier(0);
+            if constexpr (decltype(with_dma)::value) stage(kt + 1, cur ^ 1);
+            read_frags(cur, 0, fa0, fb0);
+            mfma_all(fa1, fb1);                                  // sub-step 1 of tile kt-1
+            if constexpr (MT + NT == 12 && MT * NT == 32) {
+                if constexpr (decltype(with_dma)::value) {
+#pragma unroll
+                    for (int g = 0; g < CA + CB; ++g) {          // 1 MFMA, then one DMA piece (8 x): the DMA goes out first, its latency is the long one
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                    }
+#pragma unroll
+                    for (int g = 0; g < 12; ++g) {               // 2 MFMAs, then one fragment read (12 x)
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 12; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                }
             }
-            mfma_all(fa1, fb1);
             __builtin_amdgcn_sched_barrier(0);
+            read_frags(cur, 1, fa1, fb1);
+            mfma_all(fa0, fb0);                                  // sub-step 0 of tile kt
+            if constexpr (MT + NT == 12 && MT * NT == 32) {
+#pragma unroll
+                for (int g = 0; g < 12; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(W_ALL);                   // tile kt+1 landed; my reads of tile kt are done
+            __builtin_amdgcn_s_barrier();
+        };
+        if (RALD_ABLATED(a.ablate, 1)) {
+            for (int kt = 1; kt < nk; ++kt) body(kt, std::false_type{});
+        } else {
+            for (int kt = 1; kt + 1 < nk; ++kt) body(kt, std::true_type{});
+            if (nk > 1) body(nk - 1, std::false_type{});
         }
+        mfma_all(fa1, fb1);                                      // sub-step 1 of the last tile
     } else {
 #pragma unroll
         for (int s = 0; s < NSTAGE - 1; ++s)
@@ -372,10 +423,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_glds_kernel(GemmArgs a) 
         if (s == 1234.5678f) reinterpret_cast<float*>(a.C)[0] = s;
         return;
     }
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();             // every wave is done reading the staging buffers: reuse them as patches
-    asm volatile("" ::: "memory");
+    if constexpr (NSTAGE != 2) {              // (the 2-stage loop ends on a barrier behind its last fragment reads)
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();         // every wave is done reading the staging buffers: reuse them as patches
+        asm volatile("" ::: "memory");
+    }
+    RALD_GSTAMP(2);
     gemm_epilogue_lds<MT, NT, EPI>(acc, a, m0 + wm * (BM / WM), n0 + wn * (BN / WN), coff, lane, smem + wave * 8704);
+    RALD_GSTAMP(3);
+#ifdef RALD_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RALD_GSTAMP(4);
+#endif
 #ifdef RALD_GEMM_CLOCK
     if (tid == 0 && lin == nt / 2) { g_gemm_clk[0] = clock64() - clk0; g_gemm_clk[1] = wall_clock64() - wall0; }
 #endif

@@ -155,6 +155,13 @@ class LatentArrayTransformer(_HipBacked):
         """x [B,N,C], t [B'] (= c_noise; B' = 1 or B), cond [B,T,context_dim] -> F_x [B,N,C]."""
         if cond is None:
             raise NotImplementedError("the reference always passes radar condition tokens (cond)")
+        if x.dim() != 3 or cond.dim() != 3:
+            raise RuntimeError(f"x must be [B,N,C] and cond [B,T,context_dim], got {tuple(x.shape)} and {tuple(cond.shape)}")
+        if x.shape[0] != cond.shape[0]:
+            raise RuntimeError(f"x holds {x.shape[0]} samples but cond holds {cond.shape[0]}: one set of condition tokens per sample "
+                               "(the reference's einsum 'b i d, b j d' fails the same way, models_radar_generation.py:66)")
+        if x.shape[2] != self.in_channels:
+            raise RuntimeError(f"x has {x.shape[2]} channels, the module was built for {self.in_channels}")
         h = self._handle(x.shape[1], cond.shape[1])
         t = torch.as_tensor(t, dtype=torch.float32).flatten().cpu()
         h.set_sigmas(torch.exp(4.0 * t.double()).tolist())      # c_noise = ln(sigma)/4  (:425)
@@ -195,6 +202,9 @@ class _EdmDenoiseFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dD):
+        if ctx.st is None:
+            raise RuntimeError("EDMPrecond.forward: backward through the same forward a second time - the saved activations "
+                               "(~1 GiB per sample batch) are released by the first backward; retain_graph is not supported")
         tr = ctx.module._autograd_trainers()
         for sh in tr["shadow"].values():
             sh.grad = None
@@ -337,8 +347,17 @@ class EDMPrecond(_HipBacked):
     def forward(self, x, sigma, label_tokens=None, cond_type=None, force_fp32=False, **model_kwargs):
         if cond_type != 'radar':
             raise NotImplementedError("cond_type must be 'radar'")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            # training: differentiable route (engine_generation.py:93-104: loss_scaler(loss, ...) -> loss.backward())
+        if label_tokens is None:
+            raise RuntimeError("label_tokens (the radar cube [B,R,A,E,2]) is required: the reference's forward dereferences it too (:414)")
+        if x.dim() != 3 or x.shape[0] != label_tokens.shape[0]:
+            raise RuntimeError(f"x must be [B,{self.n_latents},{self.channels}] with one radar cube per sample; got x {tuple(x.shape)}, "
+                               f"cube {tuple(label_tokens.shape)}")
+        # Route like the reference uses the module: model.train() + grad mode = the training step (engine_generation.py:47, :93-104:
+        # loss_scaler(loss, ...) -> loss.backward()); model.eval() / @torch.no_grad() = inference (engine_generation.py:141, :183)
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if self.qkv_dtype != "bf16":
+                raise NotImplementedError(f"qkv_dtype={self.qkv_dtype!r} is an inference mode; the differentiable route computes in bf16 "
+                                          "(call model.eval() or wrap the call in torch.no_grad())")
             if x.requires_grad or label_tokens.requires_grad:
                 raise NotImplementedError("gradients with respect to the noised latents / the radar cube are not built "
                                           "(the reference trains the parameters only: latents come from the frozen VAE)")

@@ -215,3 +215,13 @@ def test_shipped_library_reads_no_environment_variable():
     und = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "getenv" not in und
     assert _lib.lib().rald_build_flags() == 0
+
+
+def test_module_forward_checks_batch_sizes_before_touching_the_gpu():
+    """VERDICT r02 weak #5: a condition batch that does not match x used to reach the kernels (out-of-bounds reads)."""
+    from rald_amd import models_radar_generation as G
+    m = G.LatentArrayTransformer(in_channels=32, t_channels=256, n_heads=8, d_head=64, depth=1)
+    with pytest.raises(RuntimeError, match="one set of condition tokens per sample"):
+        m(torch.zeros(3, 512, 32), torch.tensor([0.1]), cond=torch.zeros(2, 64, 512))
+    with pytest.raises(RuntimeError, match="channels"):
+        m(torch.zeros(2, 512, 16), torch.tensor([0.1]), cond=torch.zeros(2, 64, 512))
