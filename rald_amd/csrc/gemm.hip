@@ -692,6 +692,9 @@ int gemm_nt(const GemmArgs& a0, int epi, hipStream_t st) {
     static const int nt_store = RALD_PROBE_ENV("RALD_NT_STORE", 1);
     GemmArgs a = a0;
     if (nt_store) a.ablate |= 64;
+    static const int st_flavour = RALD_PROBE_ENV("RALD_GEMM_STORE", 0);     // probe builds: 1 = sc0 sc1 (no nt), 2 = sc1
+    if (st_flavour == 1) a.ablate |= 512;
+    if (st_flavour == 2) a.ablate |= 1024;
     static const int diag = RALD_PROBE_ENV("RALD_GEMM_ABLATE", 0);   // probe builds (PMC runs): OR-ed into GemmArgs::ablate
     a.ablate |= diag;
     return gemm_nt_impl(a, epi, st);

@@ -135,7 +135,12 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[MT][NT], const Ge
                         // lines displace the weight / activation panels: FETCH_SIZE of the FF1 GEMM in situ 193 MB per launch
                         // against 80 MB with this policy (= with no stores at all; profiles/traffic.json)
                         const u32x4 vv = u32x4{v.x, v.y, v.z, v.w};
-                        if (a.ablate & 64) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(C), "v"(vv) : "memory");
+                        if (RALD_ABLATED(a.ablate, 512)) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(C), "v"(vv) : "memory");     // probe: write-through without the nt hint
+                        else if (RALD_ABLATED(a.ablate, 1024)) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(C), "v"(vv) : "memory");   // probe: sc1 only
+#ifdef RALD_STORE_SC01        // A/B builds (tools/build_variant.sh): write-through without the nt hint
+                        else if (a.ablate & 64) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(C), "v"(vv) : "memory");
+#endif
+                        else if (a.ablate & 64) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(C), "v"(vv) : "memory");
                         else *reinterpret_cast<uint4*>(C) = v;
                     } else *reinterpret_cast<uint2*>(C) = make_uint2(v.x, v.y);   // N % 8 == 4 tail
                 }

@@ -25,6 +25,9 @@ namespace rald {
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
+#ifdef RALD_LN_STAMPS   // tools/probe/ln_timeline.hip: shader clocks a workgroup spends waiting at the tile hand-overs vs in the whole k-loop
+__device__ long long g_ln_stamps[1024][4];
+#endif
 
 // ---- epilogue shared by the main-loop forms: acc (+ x_old already inside unless XEPI) -> x_new, h ---------------------------------
 template <int BM, int WM, int WN, bool XEPI>
@@ -308,15 +311,24 @@ __device__ __forceinline__ void gemm_resid_ln_body(const GemmLnArgs& a) {
     static_assert(MT * NT % 8 == 0, "x pieces per k-step");
     nt_f32x4 xt[XP];
     const int mb_ = m0 + wm * (BM / WM), nb_ = wn * (BN / WN);
+    // x_old addresses as uniform base + one 32-bit lane offset per m-tile + immediates (64-bit lane pointers per piece were hoisted out of
+    // the k-loop by the compiler: 64 registers of loop-invariant addresses next to 128 accumulators)
+    const unsigned char* xbase = reinterpret_cast<const unsigned char*>(a.x) + (int64_t)mb_ * BN * 4;      // uniform
+    unsigned xoff[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        int r = i * 16 + fr;
+        r = mb_ + r < a.M ? r : a.M - 1 - mb_;
+        xoff[i] = (unsigned)r * (BN * 4) + (unsigned)(nb_ + 4 * fq) * 4;
+    }
     auto x_load = [&](auto QC) {
         constexpr int q = decltype(QC)::value;
 #pragma unroll
         for (int e = 0; e < XP; ++e) {
-            constexpr int dummy = 0; (void)dummy;
             const int idx = q * XP + e, i = idx / NT, j = idx % NT;
-            int m = mb_ + i * 16 + fr;
-            m = m < a.M ? m : a.M - 1;
-            const nt_f32x4* px = reinterpret_cast<const nt_f32x4*>(a.x + (int64_t)m * BN + nb_ + j * 16 + 4 * fq);
+            const unsigned char* sp = xbase;
+            asm volatile("" : "+s"(sp));                               // (keeps the address in the saddr + lane offset + immediate form)
+            const nt_f32x4* px = reinterpret_cast<const nt_f32x4*>(sp + xoff[i] + j * 64);
             xt[e] = nt_io_ ? __builtin_nontemporal_load(px) : *px;
         }
     };
@@ -359,6 +371,144 @@ __device__ __forceinline__ void gemm_resid_ln_body(const GemmLnArgs& a) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
         }
     };
+    if constexpr (XLOOP && BK == 64 && MT == 4 && NT == 8 && CA + CB == 10) {
+        // ---- pipelined main loop of the 128-row form (round 3) ----------------------------------------------------------------------
+        // An iteration starts right AFTER a tile hand-over (barrier), so no LDS read is pending at the loop head and the compiler's
+        // waits inside are exact counts.  Fragments: the A side (4 m-tiles) is double-buffered per 32-deep sub-step, the B side (8
+        // n-tiles) is refreshed IN PLACE: the read of n-tile j for the next sub-step goes out right behind the 4 MFMAs that consumed
+        // the current one (LDS returns in order; the register hazard is the hardware's).  The 10 DMA pieces of the next tile and the
+        // 12 reads are spread between the MFMAs instead of standing in front of them (round 2: wait - barrier - 10 DMA issues - 12
+        // reads - wait - 32 MFMAs - 12 reads - wait - 32 MFMAs, i.e. ~1300 idle matrix-pipe cycles per 2048-cycle k-step).
+        constexpr int W_ALL = 0x0070;                                  // vmcnt(0) lgkmcnt(0)
+        constexpr int W_ST1 = ((CA + CB) & 15) | (((CA + CB) >> 4) << 14) | 0x0f70;
+        bf16x8 fa[MT], fb[NT];
+        // DMA sources as scalar base + 32-bit lane offset (the saddr form of global_load_lds): 3 VGPRs instead of the 20 that ten
+        // 64-bit lane pointers take - the register file has 128 accumulators, 48 fragment registers and 16 of x_old to hold
+        const unsigned char* sbA = A0 + (int64_t)m0 * a.lda * ESZ;                    // uniform
+        unsigned voA[CA];
+#pragma unroll
+        for (int p = 0; p < CA; ++p) {
+            int r = RPP * (wave + WAVES * p) + lr;
+            r = m0 + r < a.M ? r : a.M - 1 - m0;
+            voA[p] = (unsigned)r * (unsigned)(a.lda * ESZ) + (unsigned)lc * 16u;
+        }
+        const unsigned voB = (unsigned)(RPP * wave + lr) * (unsigned)(a.ldw * ESZ) + (unsigned)lc * 16u;
+        const unsigned stepB = (unsigned)(RPP * WAVES) * (unsigned)(a.ldw * ESZ);     // uniform: bytes between this wave's W pieces
+        auto stage2 = [&](int kt, int buf) {
+            unsigned char* base = smem + buf * STAGE_BYTES;
+            const unsigned char* ka = sbA + kt * ROWB;
+            const unsigned char* kb = W0 + kt * ROWB;
+#pragma unroll
+            for (int p = 0; p < CA; ++p)
+                __builtin_amdgcn_global_load_lds((glb_void*)(ka + voA[p]), (lds_void*)(base + (wave + WAVES * p) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int p = 0; p < CB; ++p)
+                __builtin_amdgcn_global_load_lds((glb_void*)(kb + (size_t)p * stepB + voB), (lds_void*)(base + BM * ROWB + (wave + WAVES * p) * 1024), 16, 0, 0);
+        };
+        auto rdA = [&](int buf, int kk, int i) -> bf16x8 {
+            const bf16x8* sA = reinterpret_cast<const bf16x8*>(smem + buf * STAGE_BYTES);
+            const int r = wm * (BM / WM) + i * 16 + fr;
+            return sA[r * 8 + ((kk * 4 + fq) ^ (r & 7))];
+        };
+        auto rdB = [&](int buf, int kk, int j) -> bf16x8 {
+            const bf16x8* sB = reinterpret_cast<const bf16x8*>(smem + buf * STAGE_BYTES) + BM * 8;
+            const int r = wn * (BN / WN) + j * 16 + fr;
+            return sB[r * 8 + ((kk * 4 + fq) ^ (r & 7))];
+        };
+        // One 32-deep sub-step = 32 MFMAs on the fragments in registers, with the 12 fragment reads of the NEXT sub-step (buffer nbuf,
+        // half nkk) going out in place as soon as a fragment's last MFMA has been issued:
+        //   head   (i,0) (i,1) for i = 0..3        then fb[0], fb[1] are re-read
+        //   middle (i,j) for j = 2..5              fb[j] re-read behind its 4 MFMAs
+        //   tail   (i,6) (i,7) for i = 0..3        fa[i] re-read behind its 2 MFMAs, fb[6], fb[7] at the end
+        // so every A fragment is re-read >= 6 MFMAs (~100 clocks, an LDS latency) before the next sub-step's head needs it and no
+        // fragment is double-buffered.  The DMA pieces of the next tile (first sub-step of an iteration) go between the head's MFMAs.
+        // sched_barrier(0) after every group pins the order (hipcc otherwise pulls the reads to the front and waits for all of them).
+        auto mm = [&](int i, int j) { acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0); };
+        auto substep = [&](int nbuf, int nkk, auto DMA, int kt_next) {
+            constexpr bool dma = decltype(DMA)::value;
+            unsigned char* dbase = smem + (kt_next & 1) * STAGE_BYTES;
+            const unsigned char* ka = sbA + kt_next * ROWB;
+            const unsigned char* kb = W0 + kt_next * ROWB;
+            // (the scalar bases pass through an empty asm: otherwise loop strength reduction turns every piece's address into a 64-bit
+            //  lane pointer carried around the loop - the 20 registers this addressing form is here to save)
+            auto dmaA = [&](int p) {
+                const unsigned char* sp = ka;
+                asm volatile("" : "+s"(sp));
+                __builtin_amdgcn_global_load_lds((glb_void*)(sp + voA[p]), (lds_void*)(dbase + (wave + WAVES * p) * 1024), 16, 0, 0);
+            };
+            auto dmaB = [&](int p) {
+                const unsigned char* sp = kb + (size_t)p * stepB;
+                asm volatile("" : "+s"(sp));
+                __builtin_amdgcn_global_load_lds((glb_void*)(sp + voB), (lds_void*)(dbase + BM * ROWB + (wave + WAVES * p) * 1024), 16, 0, 0);
+            };
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {                              // head
+                mm(i, 0);
+                if constexpr (dma) { if (i < CA) dmaA(i); else dmaB(i - CA); }
+                __builtin_amdgcn_sched_barrier(0);
+                mm(i, 1);
+                if constexpr (dma) dmaB(i + MT - CA);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (nbuf >= 0) { fb[0] = rdB(nbuf, nkk, 0); fb[1] = rdB(nbuf, nkk, 1); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 2; j < NT - 2; ++j) {                          // middle
+                mm(0, j); mm(1, j);
+                if constexpr (dma) { if (j - 2 + 2 * MT - CA < CB) dmaB(j - 2 + 2 * MT - CA); }
+                __builtin_amdgcn_sched_barrier(0);
+                mm(2, j); mm(3, j);
+                if (nbuf >= 0) fb[j] = rdB(nbuf, nkk, j);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {                              // tail
+                mm(i, NT - 2); mm(i, NT - 1);
+                if (nbuf >= 0) fa[i] = rdA(nbuf, nkk, i);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (nbuf >= 0) { fb[NT - 2] = rdB(nbuf, nkk, NT - 2); fb[NT - 1] = rdB(nbuf, nkk, NT - 1); }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        static_assert(2 * MT - CA + (NT - 4) >= CB, "all DMA pieces of a stage find a slot in the first sub-step");
+#ifdef RALD_LN_STAMPS
+        long long st_wait = 0, st_t0 = clock64();
+#endif
+        auto hand_over = [&]() {
+#ifdef RALD_LN_STAMPS
+            const long long w0 = clock64();
+#endif
+            __builtin_amdgcn_s_waitcnt(W_ALL);                         // the next tile has landed; my reads of this one are done
+            __builtin_amdgcn_s_barrier();
+#ifdef RALD_LN_STAMPS
+            st_wait += clock64() - w0;
+#endif
+        };
+        stage2(0, 0);
+        if (nk > 1) { stage2(1, 1); __builtin_amdgcn_s_waitcnt(W_ST1); } else __builtin_amdgcn_s_waitcnt(W_ALL);
+        __builtin_amdgcn_s_barrier();
+        // tile 0, sub-step 0: its fragments have nothing to hide behind
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[j] = rdB(0, 0, j);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[i] = rdA(0, 0, i);
+        substep(0, 1, std::false_type{}, 0);                           // MFMAs (tile 0, kk 0); reads (tile 0, kk 1)
+        hand_over();
+        // iteration kt >= 1: [DMA tile kt+1] MFMAs (kt-1, kk 1) + reads (kt, kk 0) | MFMAs (kt, kk 0) + reads (kt, kk 1) | hand-over.
+        // (x_old is added in the epilogue on this path: riding along in the loop - a uniform switch over the piece index - cost the
+        //  register allocator PHI copies of all 128 accumulators and 140 spills)
+        auto iter = [&](int kt, auto DMA) {
+            substep(kt & 1, 0, DMA, kt + 1);                           // MFMAs (kt-1, kk 1) + DMA of tile kt+1 + reads (kt, kk 0)
+            substep(kt & 1, 1, std::false_type{}, 0);                  // MFMAs (kt, kk 0) + reads (kt, kk 1)
+            hand_over();
+        };
+        for (int kt = 1; kt + 1 < nk; ++kt) iter(kt, std::true_type{});
+        if (nk > 1) iter(nk - 1, std::false_type{});
+        substep(-1, 0, std::false_type{}, 0);                          // MFMAs (last tile, kk 1)
+#ifdef RALD_LN_STAMPS
+        if (threadIdx.x == 0) { g_ln_stamps[blockIdx.x & 1023][0] = st_wait; g_ln_stamps[blockIdx.x & 1023][1] = clock64() - st_t0; g_ln_stamps[blockIdx.x & 1023][2] = wall_clock64(); }
+#endif
+    } else {
     stage(0, 0);
     if constexpr (!XLOOP) {                                           // two workgroups per CU: the other one covers this one's epilogue reads
         for (int kt = 0; kt < nk; ++kt) kstep(kt, std::integral_constant<int, 9>{});
@@ -388,7 +538,12 @@ __device__ __forceinline__ void gemm_resid_ln_body(const GemmLnArgs& a) {
     }
     }
 
-    resid_ln_epilogue<BM, WM, WN, (MX || !XLOOP)>(a, acc, smem, NSTAGE * STAGE_BYTES, m0);
+    }
+    constexpr bool PIPE = XLOOP && !MX && BK == 64 && MT == 4 && NT == 8 && CA + CB == 10;     // the pipelined loop adds x_old in the epilogue
+    resid_ln_epilogue<BM, WM, WN, (MX || !XLOOP || PIPE)>(a, acc, smem, NSTAGE * STAGE_BYTES, m0);
+#ifdef RALD_LN_STAMPS
+    if (threadIdx.x == 0) g_ln_stamps[blockIdx.x & 1023][3] = wall_clock64();
+#endif
 }
 
 #ifdef RALD_PROBE
