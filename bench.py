@@ -32,6 +32,38 @@ sys.path.insert(0, ROOT)
 
 GFLOP_PER_NFE = 132.18          # SURVEY.md §8d / BASELINE.md §3 (multiply-add = 2 FLOP)
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip table)
+PEAK_HBM_GBS = 8000.0           # MI355X HBM3E (same table; ~6.3 TB/s is what a streaming copy reaches)
+
+
+def source_fingerprint():
+    """sha256 over the kernel / host sources of the library (rald_amd/csrc/*.hip, *.h, include/*.h): identifies the code a number was
+    measured on where no git metadata travels (the GPU box gets a snapshot without .git).  profiles/traffic.json carries the same
+    fingerprint of the tree its counters were collected on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "rald_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "rald_amd", "csrc", "*.h")) +
+                    glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
+def git_commit():
+    """HEAD of the tree this line was measured on (the GPU box receives a snapshot without .git: the builder writes BUILD_COMMIT
+    beside bench.py before a run it wants stamped; otherwise 'unknown')."""
+    try:
+        import subprocess
+        out = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=5)
+        if out.returncode == 0 and out.stdout.strip():
+            dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--untracked-files=no"], capture_output=True, text=True, timeout=5)
+            return out.stdout.strip() + ("+dirty" if dirty.stdout.strip() else "")
+    except Exception:
+        pass
+    try:
+        return open(os.path.join(ROOT, "BUILD_COMMIT")).read().strip()
+    except Exception:
+        return "unknown"
 
 
 # variables that only a PROBE build of the library reads (rald_amd/csrc/common.h), plus the library override itself
@@ -161,7 +193,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="samples per GPU per NFE")
+    ap.add_argument("--batch", type=int, default=128, help="samples per GPU per NFE")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -192,7 +224,8 @@ def main():
         h.denoise(x, cache, 0)
     barrier(world)
     elapsed = time.perf_counter() - t0
-    ff1_ms, ff1_launches = h.profile_end()
+    kinds = h.profile_end_kinds()
+    ff1_ms, ff1_launches = kinds[0]
     elapsed = max_over_ranks(elapsed, world)
 
     total_units = world * B * args.steps
@@ -201,13 +234,35 @@ def main():
     ff1_flops = 2.0 * (B * 512) * 4096 * 512
     avg_s = (ff1_ms / max(ff1_launches, 1)) * 1e-3
     achieved = ff1_flops / avg_s / 1e12 if avg_s > 0 else 0.0
-    traffic = None
+    traffic, traffic_commit, tj = None, None, {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(f"ff1_geglu_gemm_B{B}")
+            tj = json.load(open(tpath))
+            traffic = tj.get(f"ff1_geglu_gemm_B{B}")
+            traffic_commit = tj.get("_source_sha")
         except Exception:
             traffic = None
+    M = B * 512
+    # the three fused residual + LayerNorm GEMMs (x += A.W^T + b; h = AdaLN(x)): largest time share of an NFE.  Algorithmic HBM bytes per
+    # launch: A bf16 [M,K] + x fp32 read and written [M,512] + h bf16 [M,512] (+ W, once); FLOPs 2.M.512.K
+    def ln_roofline(kind, K, name):
+        ms, n = kinds[kind]
+        if n == 0:
+            return None
+        t = ms / n * 1e-3
+        flops = 2.0 * M * 512 * K
+        byt = M * K * 2 + M * 512 * (4 + 4 + 2) + 512 * K * 2 * (B if kind == 2 else 1)      # (kind 2: one folded weight matrix per sample)
+        hbm, mf = byt / t / 1e9, flops / t / 1e12
+        bound = "hbm" if hbm / PEAK_HBM_GBS > mf / PEAK_BF16_TFLOPS else "mfma"
+        return {"kernel": name, "bound": bound, "achieved": hbm if bound == "hbm" else mf, "peak": PEAK_HBM_GBS if bound == "hbm" else PEAK_BF16_TFLOPS,
+                "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": (hbm / PEAK_HBM_GBS) if bound == "hbm" else (mf / PEAK_BF16_TFLOPS),
+                "tflops": mf, "hbm_gbs": hbm, "avg_launch_us": t * 1e6, "launches_timed": n,
+                "algorithmic_bytes_per_launch": byt, "algorithmic_flop_per_launch": flops,
+                "traffic": (tj.get("in_situ_bytes_per_launch", {}) or {}).get(f"{name.split(' ')[0]}_B{B}")}
+    roofline_ln = [r for r in (ln_roofline(1, 512, "gemm_resid_ln_K512_attn1 (to_out + residual + AdaLN)"),
+                               ln_roofline(2, 512, "gemm_resid_ln_K512_attn2 (folded cross-attention output + residual + AdaLN, per-sample weights)"),
+                               ln_roofline(3, 2048, "gemm_resid_ln_K2048_ff2 (ff.net.2 + residual + AdaLN)")) if r]
 
     out = {
         "metric": "denoising steps/sec (whole node)", "value": value, "unit": "sample*NFE/s",
@@ -216,14 +271,15 @@ def main():
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "configs[2]: kl_d512_m512_l32_d24_edm denoiser NFE, 512x32 latents, 64x512 radar condition tokens (cached)",
                    "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"batch-sharded x{world}, no data-path collective",
-                   "weights": "seeded random (rald_amd.weights, seed 0)", "env": env},
+                   "weights": "seeded random (rald_amd.weights, seed 0)", "env": env, "commit": git_commit(), "source_sha": source_fingerprint()},
         "whole_path_tflops": value * GFLOP_PER_NFE / 1e3,
         "heun_steps_per_s": value * 18.0 / 35.0, "samples_per_s_18step": value / 35.0,
         "roofline": {"bound": "mfma", "kernel": "rald::gemm_nt_glds_kernel<256,256,4,2,2,EPI_GEGLU> (FF1: [B*512,512]x[512,4096]^T, GEGLU epilogue)",
                      "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic, "traffic_measured_on_source_sha": traffic_commit,
                      "launches_timed": ff1_launches, "avg_launch_us": avg_s * 1e6,
                      "algorithmic_flop_per_launch": ff1_flops},
+        "roofline_resid_ln": roofline_ln,
     }
     log(f"GPU: {value:.1f} sample*NFE/s, FF1 kernel {achieved:.0f} TFLOP/s over {ff1_launches} launches")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -242,16 +298,23 @@ def main():
             import threading
             limit = float(os.environ.get("RALD_BENCH_LEG_TIMEOUT", "600"))
 
+            leg_state = {"leg": None, "started": None}
+
             def _bail():
+                # a hung collective: print what was measured, say WHICH leg hung, and fail the run (a hang must not read as a pass)
                 if rank == 0:
                     snap = dict(out)
-                    snap["secondary_legs"] = f"timed out after {limit:.0f} s (headline unaffected)"
+                    snap["secondary_legs"] = {"status": "TIMEOUT", "leg": leg_state["leg"], "limit_s": limit,
+                                              "note": "the headline above was measured before the legs started; exit code 4"}
                     print(json.dumps(snap), flush=True)
-                os._exit(0)
+                print(f"[bench] rank {rank}: leg {leg_state['leg']!r} did not finish within {limit:.0f} s - exiting 4", file=sys.stderr, flush=True)
+                os._exit(4)
             watchdog = threading.Timer(limit, _bail)
             watchdog.daemon = True
             watchdog.start()
         for name, fn in (("config4", bench_extras.config4_leg), ("ddp_step", bench_extras.ddp_step_leg)):
+            if world > 1:
+                leg_state["leg"] = name
             try:
                 barrier(world)
                 res = fn(rank, world)

@@ -30,6 +30,10 @@ int rald_version(void);
  * switches, some of which skip work (no DMA in a main loop, no epilogue stores).  0 for the shipped library, which reads no
  * environment variable at all; bench.py refuses to measure a library that reports anything else. */
 int rald_build_flags(void);
+/* Diagnostic (synchronises the device): how many times a lane clamped a value while writing an fp16 partial-sum slab since the last
+ * reset.  The small-batch paths (<= 2 samples) pass per-head / split-K partial sums between kernels as fp16 x 2^-6, saturating at
+ * +-4.19e6; a non-zero count means a result was clipped.  Returns -1 on a HIP error. */
+int64_t rald_debug_f16_saturation_count(int32_t reset);
 
 /* ------------------------------------------------------------------------------------------
  * Denoiser: EDMPrecond + LatentArrayTransformer  (model/models_radar_generation.py:171-233,
@@ -68,7 +72,8 @@ int rald_dit_reserve(rald_dit* h, int32_t max_batch);
  * captured library calls into a hipGraph must re-capture when the value differs from the one read after capture: the
  * graph's kernels hold pointers into those buffers. */
 int64_t rald_dit_workspace_generation(const rald_dit* h);
-/* Two-stream schedule of an NFE (rald_dit_denoise / rald_dit_sample): from `min_batch` samples up (default 128) the batch runs as
+/* Two-stream schedule of an NFE (rald_dit_denoise / rald_dit_sample): from `min_batch` samples up (default 256; measured: +1.9 % there,
+ * nothing at 128) the batch runs as
  * two half-batches on two HIP streams - the caller's and a handle-owned one, forked from and joined back into `stream` with events,
  * so the caller sees ordinary stream semantics.  Every CU of one launch runs the same phase at the same time (matrix loop, then the
  * store-heavy epilogue); a second independent half-batch fills those holes.  Each half runs exactly the kernels a batch of its size
@@ -114,6 +119,11 @@ int rald_dit_sample(rald_dit* h, const float* latents, int32_t batch, const void
  * launch stream (up to 4096 launches); end synchronises those events and returns their sum. */
 int rald_dit_profile_begin(rald_dit* h);
 int rald_dit_profile_end(rald_dit* h, double* total_ms, int32_t* launches);
+/* The same bracket also times the three fused residual + LayerNorm GEMMs of a block (the largest time share of an NFE); this form
+ * returns all four kinds: [0] FF1 GEGLU GEMM, [1] attn1.to_out + residual + AdaLN (K = 512), [2] attn2 output projection + residual
+ * + AdaLN (K = 512), [3] ff.net.2 + residual + AdaLN (K = 2048).  total_ms4 / launches4 point at 4 elements each.  Batches that
+ * take another engine for a kind (small M) report 0 launches there. */
+int rald_dit_profile_end_kinds(rald_dit* h, double* total_ms4, int32_t* launches4);
 
 /* ------------------------------------------------------------------------------------------
  * Set-latent autoencoder: KLAutoEncoder, query_type='mix' or 'learnable'  (model/models_ae.py:284-432)

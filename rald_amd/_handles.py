@@ -153,7 +153,7 @@ class DitHandle:
         return out
 
     def set_two_stream_min_batch(self, min_batch: int) -> None:
-        """From `min_batch` samples up an NFE runs as two half-batches on two HIP streams (default 128; 0 = never)."""
+        """From `min_batch` samples up an NFE runs as two half-batches on two HIP streams (default 256; 0 = never)."""
         self._graphs.clear()                           # the workspace is re-planned
         check(lib().rald_dit_set_two_stream_min_batch(self._h, int(min_batch)))
 
@@ -164,6 +164,12 @@ class DitHandle:
         ms, n = C.c_double(0), C.c_int32(0)
         check(lib().rald_dit_profile_end(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def profile_end_kinds(self):
+        """[(ms, launches)] x 4: FF1 GEGLU GEMM, attn1 / attn2 output projection + residual + AdaLN (K = 512), FF2 + residual + AdaLN."""
+        ms, n = (C.c_double * 4)(), (C.c_int32 * 4)()
+        check(lib().rald_dit_profile_end_kinds(self._h, ms, n))
+        return [(ms[i], n[i]) for i in range(4)]
 
     def reserve(self, batch: int) -> None:
         if batch > self._reserved:
@@ -202,7 +208,8 @@ class DitHandle:
 def op_gemm_nt(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = 0,
                C_inout: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
     """A [batch?,M,K] bf16, B [batch?,N,K] bf16 -> C.  epilogue 0 bf16, 1 f32, 2 f32 accumulate into
-    C_inout, 3 GEGLU (B rows / bias pre-packed), 4 softmax over aligned groups of 64 columns (exp2 units, bf16)."""
+    C_inout, 3 GEGLU (B rows / bias pre-packed), 4 softmax over aligned groups of 64 columns (exp2 units, bf16), 5 fp16 slab =
+    2^-6 x the product, saturating (the split-K partial sums of the small-batch path)."""
     batched = A.dim() == 3 or B.dim() == 3
     batch = (A.shape[0] if A.dim() == 3 else B.shape[0]) if batched else 1
     M, K = A.shape[-2], A.shape[-1]
@@ -214,7 +221,7 @@ def op_gemm_nt(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = 
         out = C_inout
     else:
         shape = (batch, M, nc) if batched else (M, nc)
-        out = torch.empty(shape, device=A.device, dtype=torch.bfloat16 if epilogue in (0, 3, 4) else torch.float32)
+        out = torch.empty(shape, device=A.device, dtype=torch.float16 if epilogue == 5 else (torch.bfloat16 if epilogue in (0, 3, 4) else torch.float32))
     sC = out.stride(0) if out.dim() == 3 else 0
     check(lib().rald_op_gemm_nt(C.c_void_p(_ptr(A)), A.stride(-2), sA, C.c_void_p(_ptr(B)), B.stride(-2), sB,
                                 C.c_void_p(_ptr(out)), out.stride(-2), sC,

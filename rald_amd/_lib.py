@@ -42,6 +42,7 @@ SIGNATURES = {
     "rald_dit_destroy": (None, [c_void_p]),
     "rald_dit_load_weight": (c_int, [c_void_p, c_char_p, c_void_p, c_i64]),
     "rald_dit_finalize": (c_int, [c_void_p]),
+    "rald_debug_f16_saturation_count": (c_i64, [c_int]),
     "rald_dit_reserve": (c_int, [c_void_p, c_int]),
     "rald_dit_workspace_generation": (c_i64, [c_void_p]),
     "rald_dit_set_two_stream_min_batch": (c_int, [c_void_p, c_int]),
@@ -55,6 +56,7 @@ SIGNATURES = {
     "rald_dit_sample": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_float, c_float, c_float, c_void_p, c_void_p]),
     "rald_dit_profile_begin": (c_int, [c_void_p]),
     "rald_dit_profile_end": (c_int, [c_void_p, C.POINTER(C.c_double), C.POINTER(c_int)]),
+    "rald_dit_profile_end_kinds": (c_int, [c_void_p, C.POINTER(C.c_double), C.POINTER(c_int)]),
     "rald_ae_create": (c_int, [C.POINTER(AeConfig), C.POINTER(c_void_p)]),
     "rald_ae_destroy": (None, [c_void_p]),
     "rald_ae_load_weight": (c_int, [c_void_p, c_char_p, c_void_p, c_i64]),

@@ -22,6 +22,13 @@ int rald_build_flags(void) {
 #endif
 }
 
+int64_t rald_debug_f16_saturation_count(int32_t reset) {
+    unsigned a = 0, b = 0;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (f16_saturation_gemm(&a, reset != 0) || f16_saturation_attn(&b, reset != 0)) return -1;
+    return (int64_t)a + (int64_t)b;
+}
+
 void rald_dit_default_config(rald_dit_config* c) {
     c->n_latents = 512; c->channels = 32; c->depth = 24; c->n_heads = 8; c->d_head = 64; c->t_channels = 256;
     c->context_dim = 512; c->n_cond_tokens = 64; c->with_radar_enc = 1; c->enc_hidden_ch = 64; c->enc_radar_ch = 16;
@@ -92,6 +99,14 @@ int rald_dit_profile_end(rald_dit* h, double* total_ms, int32_t* launches) {
     int n = 0;
     int rc = h->impl.profile_end(total_ms, &n);
     *launches = n;
+    return rc;
+}
+
+int rald_dit_profile_end_kinds(rald_dit* h, double* total_ms4, int32_t* launches4) {
+    RALD_CHECK(h && total_ms4 && launches4, "rald_dit_profile_end_kinds: null argument");
+    int n[Dit::PROF_KINDS];
+    int rc = h->impl.profile_end_kinds(total_ms4, n);
+    for (int k = 0; k < Dit::PROF_KINDS; ++k) launches4[k] = n[k];
     return rc;
 }
 

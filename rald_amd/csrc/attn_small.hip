@@ -82,6 +82,13 @@ __device__ __forceinline__ bf16x8 acc_frag(const f32x16& x, int s, float scale) 
 // kernels is issue-bound (~45 clocks per store instruction, guide T21)
 // f16 = the slabs are fp16, scaled by 2^-6 and saturated (range +-4.2e6, 11 mantissa bits: below the bf16 rounding of the operands that
 // produced them; halves the 8 MB of slab traffic per sub-block: NFE -3 % at B = 1, -6.5 % at B = 2); part_row0 then points at halves.
+// Diagnostic: elements whose fp16 slab value was clamped (|v| >= 65504 * 64 = 4.19e6).  Never expected; the stress tests assert 0.
+__device__ unsigned g_f16_sat_attn;
+int f16_saturation_attn(unsigned* count, bool reset) {
+    RALD_HIP(hipMemcpyFromSymbol(count, HIP_SYMBOL(g_f16_sat_attn), sizeof(unsigned)));
+    if (reset) { const unsigned z = 0; RALD_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_f16_sat_attn), &z, sizeof(unsigned))); }
+    return 0;
+}
 __device__ __forceinline__ void store_part_tile(float* part_row0, int n0, const f32x16& acc, float* patch, int lane, bool f16) {
     const int c = lane & 31, hf = lane >> 5;
 #pragma unroll
@@ -96,6 +103,7 @@ __device__ __forceinline__ void store_part_tile(float* part_row0, int n0, const 
             h4 hv;
             hv[0] = (_Float16)fminf(fmaxf(v.x * SC, -LIM), LIM); hv[1] = (_Float16)fminf(fmaxf(v.y * SC, -LIM), LIM);
             hv[2] = (_Float16)fminf(fmaxf(v.z * SC, -LIM), LIM); hv[3] = (_Float16)fminf(fmaxf(v.w * SC, -LIM), LIM);
+            if (fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))) * SC >= LIM) atomicAdd(&g_f16_sat_attn, 1u);
             *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(part_row0) + (int64_t)row * 512 + n0 + 4 * ch) = hv;
         } else *reinterpret_cast<float4*>(part_row0 + (int64_t)row * 512 + n0 + 4 * ch) = v;
     }

@@ -122,11 +122,14 @@ struct Dit {
     // then the store-heavy epilogue; an HBM-bound kernel leaves the matrix cores idle): a second, independent half-batch fills
     // those holes.  Each half runs exactly the kernels a batch of that size runs alone, so results are bit-identical to two
     // sequential calls.  split_min = 0 turns it off.
-    int split_min = 128;
+    int split_min = 256;     // measured on MI355X (tools/ab_two_stream.py): B = 128 22.35 vs 22.08 ms unsplit (no gain: a batch of 128 already
+                             // runs two rounds of tiles per kernel and is out of step by itself), B = 256 44.5 vs 45.3 ms (+1.9 %)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool fork_pending = false;
-    int split_sizes(int B, int& b0) const { b0 = ((B / 2 + 7) / 8) * 8; return split_min > 0 && B >= split_min && b0 < B; }
+    // (the first half is a multiple of 64 samples: the GEMMs' per-tile k-offsets repeat every 256 row tiles, so both halves see the
+    //  offsets they would see inside the whole batch)
+    int split_sizes(int B, int& b0) const { b0 = ((B / 2 + 32) / 64) * 64; return split_min > 0 && B >= split_min && b0 >= 64 && b0 < B; }
     // condition cache header + registry (BlobRegistry above)
     static constexpr uint32_t COND_MAGIC = 0x52414c44u;          // "RALD"
     static constexpr int COND_HEADER_BYTES = BLOB_HEADER_BYTES;
@@ -135,11 +138,16 @@ struct Dit {
     BlobHeader cond_header(int B) const;
 
     // live timing of the dominant kernel (the FF1 GEGLU GEMM) with HIP events on the launch stream
+    // kinds: 0 = FF1 GEGLU GEMM, 1 = attn1.to_out + residual + AdaLN (K = 512), 2 = attn2 output + residual + AdaLN (K = 512, per-sample
+    // weights when folded), 3 = FF2 + residual + AdaLN (K = 2048)
+    static constexpr int PROF_KINDS = 4;
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
+    std::vector<int> prof_kind;
     int prof_used = 0;
     int profile_begin();
-    int profile_end(double* total_ms, int* launches);
+    int profile_end(double* total_ms, int* launches);                 // kind 0 only (the round-1 entry point)
+    int profile_end_kinds(double* total_ms, int* launches);           // arrays of PROF_KINDS
     ~Dit();
 
     int create();

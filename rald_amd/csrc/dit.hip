@@ -317,7 +317,7 @@ int Dit::reserve(int B) {
     RALD_TRY(alloc_work(wk[0], M));
     int b0 = 0;
     if (split_sizes(B, b0)) {                                   // the second half of a two-stream NFE works on buffers of its own
-        RALD_TRY(alloc_work(wk[1], (size_t)b0 * cfg.n_latents));
+        RALD_TRY(alloc_work(wk[1], (size_t)(B - b0 > b0 ? B - b0 : b0) * cfg.n_latents));
         if (!side) {
             RALD_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
             RALD_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
@@ -513,7 +513,7 @@ int Dit::denoise(const float* x, int B, int sigma_row, int per_sample, const voi
     RALD_TRY(cond_registry.check(cache, cond_header(B), st, "condition cache"));
     RALD_TRY(reserve(B));
     int b0 = 0;
-    if (split_sizes(B, b0) && wk[1].rows >= b0 * cfg.n_latents && side) {
+    if (split_sizes(B, b0) && wk[1].rows >= (B - b0) * cfg.n_latents && wk[0].rows >= b0 * cfg.n_latents && side) {
         // two half-batches on two streams: fork from the caller's stream, join back into it
         // The second half starts when the first one reaches its first feed-forward (about half a block later): launched together the
         // two halves would run the same kernel at the same time and compete for the same unit; half a block apart the matrix-bound
@@ -556,6 +556,14 @@ int Dit::denoise_range(const float* x, int Bfull, int b0, int B, int sigma_row, 
     const float scale = 1.0f / sqrtf((float)cfg.d_head);
     const float qscale = scale * 1.4426950408889634f;     // softmax scale and log2(e) folded into q by the projection epilogue
 
+    // live timing (rald_dit_profile_begin / _end): events around the launches of one kind on the launch stream
+    auto timed_launch = [&](int kind, auto&& launch) -> int {
+        const bool timed = timed_ok && prof_on && prof_used + 2 <= (int)prof_ev.size();
+        if (timed) RALD_HIP(hipEventRecord(prof_ev[prof_used], st));
+        RALD_TRY(launch());
+        if (timed) { RALD_HIP(hipEventRecord(prof_ev[prof_used + 1], st)); prof_kind[prof_used / 2] = kind; prof_used += 2; }
+        return 0;
+    };
     // probe builds: RALD_FUSE_LN=0 falls back to separate LayerNorm launches (A/B and debugging)
     static const bool fuse_ln = RALD_PROBE_ENV("RALD_FUSE_LN", 1) != 0;
     auto resid_ln = [&](const bf16* A, int64_t lda, const bf16* W, int64_t ldw, const float* bias, int K, const float* mnext) -> int {
@@ -736,14 +744,14 @@ int Dit::denoise_range(const float* x, int Bfull, int b0, int B, int sigma_row, 
         a1.O = ws_o; a1.ldo = D; a1.strideO = (int64_t)NL * D;
         a1.nq = NL; a1.nk = NL; a1.k_rows = NL; a1.heads = cfg.n_heads; a1.batch = B; a1.scale = scale; a1.q_prescaled = 1;
         RALD_TRY(attention_d64(a1, st));
-        RALD_TRY(resid_ln(ws_o, D, l.w_o, D, l.b_o, D, m2));                       // + norm2 for the next sub-block
+        RALD_TRY(timed_launch(1, [&] { return resid_ln(ws_o, D, l.w_o, D, l.b_o, D, m2); }));   // + norm2 for the next sub-block
         // ---- x += attn2(norm2(x, t), context)                                      (:167)
         if (fold) {
             // folded form (see cond_fold in dit.h): P = softmax over each head's 64 keys of h.Gt^T, then x += P.Ut^T + b_o (+ norm3)
             GemmArgs p1 = gemm_args(ws_h, D, Gt + (size_t)li * D * D, D, ws_q2, D, nullptr, NL, D, D);
             p1.batch = B; p1.strideA = (int64_t)NL * D; p1.strideB = (int64_t)L * D * D; p1.strideC = (int64_t)NL * D;
             RALD_TRY(gemm_nt(p1, EPI_SOFTMAX64, st));
-            RALD_TRY(resid_ln_w(ws_q2, D, Ut + (size_t)li * D * D, D, l.b_o2, D, m3, (int64_t)L * D * D));
+            RALD_TRY(timed_launch(2, [&] { return resid_ln_w(ws_q2, D, Ut + (size_t)li * D * D, D, l.b_o2, D, m3, (int64_t)L * D * D); }));
         } else {
         GemmArgs q2 = gemm_args(ws_h, D, l.w_q2, D, ws_q2, D, nullptr, M, D, D);
         q2.alpha = qscale;
@@ -761,12 +769,9 @@ int Dit::denoise_range(const float* x, int Bfull, int b0, int B, int sigma_row, 
         // ---- x += ff(norm3(x, t))                                                   (:168)
         if (fork_pending && timed_ok) { RALD_HIP(hipEventRecord(ev_fork, st)); fork_pending = false; }   // two-stream schedule: the other half starts here
         GemmArgs f1 = gemm_args(ws_h, D, l.w_ff1, D, ws_g, 4 * D, l.b_ff1, M, 8 * D, D);
-        const bool timed = timed_ok && prof_on && prof_used + 2 <= (int)prof_ev.size();
-        if (timed) RALD_HIP(hipEventRecord(prof_ev[prof_used], st));
-        RALD_TRY(gemm_nt(f1, EPI_GEGLU, st));
-        if (timed) { RALD_HIP(hipEventRecord(prof_ev[prof_used + 1], st)); prof_used += 2; }
+        RALD_TRY(timed_launch(0, [&] { return gemm_nt(f1, EPI_GEGLU, st); }));
         const float* m1_next = (li + 1 < L) ? mod + (int64_t)((li + 1) * 3) * 2 * D : nullptr;   // norm1 of the next block
-        RALD_TRY(resid_ln(ws_g, 4 * D, l.w_ff2, 4 * D, l.b_ff2, 4 * D, m1_next));
+        RALD_TRY(timed_launch(3, [&] { return resid_ln(ws_g, 4 * D, l.w_ff2, 4 * D, l.b_ff2, 4 * D, m1_next); }));
     }
     RALD_TRY(final_norm_proj(ws_x, norm_g, norm_b, w_out, x, out, M, D, C, coef, cstride, NL, st, w_out_hl));
     return 0;
@@ -774,25 +779,34 @@ int Dit::denoise_range(const float* x, int Bfull, int b0, int B, int sigma_row, 
 
 int Dit::profile_begin() {
     if (prof_ev.empty()) {
-        prof_ev.resize(2 * 4096);
+        prof_ev.resize(2 * 16384);
+        prof_kind.assign(16384, 0);
         for (auto& e : prof_ev) RALD_HIP(hipEventCreate(&e));
     }
     prof_used = 0;
     prof_on = true;
     return 0;
 }
-int Dit::profile_end(double* total_ms, int* launches) {
+int Dit::profile_end_kinds(double* total_ms, int* launches) {
     prof_on = false;
-    double tot = 0.0;
+    for (int k = 0; k < PROF_KINDS; ++k) { total_ms[k] = 0.0; launches[k] = 0; }
     for (int i = 0; i + 1 < prof_used; i += 2) {
         RALD_HIP(hipEventSynchronize(prof_ev[i + 1]));
         float ms = 0.f;
         RALD_HIP(hipEventElapsedTime(&ms, prof_ev[i], prof_ev[i + 1]));
-        tot += ms;
+        const int k = prof_kind[i / 2];
+        total_ms[k] += ms;
+        launches[k] += 1;
     }
-    *total_ms = tot;
-    *launches = prof_used / 2;
     prof_used = 0;
+    return 0;
+}
+int Dit::profile_end(double* total_ms, int* launches) {
+    double ms[PROF_KINDS];
+    int n[PROF_KINDS];
+    RALD_TRY(profile_end_kinds(ms, n));
+    *total_ms = ms[0];
+    *launches = n[0];
     return 0;
 }
 Dit::~Dit() {

@@ -259,6 +259,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_glds_kernel(GemmArgs a) 
         tn = tl % ntn;
     }
     const int m0 = tm * BM, n0 = tn * BN;
+    // k-steps are walked from a per-tile offset, wrapping around (2-stage engine): workgroups launched together otherwise ask the L2 for
+    // the same k-slice of a shared operand panel at the same moment, at every k-step (gemm_ln.hip has the measurement).  Offset =
+    // (m-tile + n-tile + batch entry) mod nk: the tiles that share an A panel (same m) or a B panel (same n) start on different slices,
+    // and a tile's offset does not depend on how many other tiles the launch has (sub-batches reproduce the whole batch bit for bit).
+    const int nk_ = a.K / BK;
+#ifndef RALD_KOFF            // off in the shipped build: see below (A/B builds: tools/build_variant.sh koff -DRALD_KOFF)
+    const int koff = 0;
+#else
+    const int koff = (NSTAGE == 2 && !RALD_ABLATED(a.ablate, 2048)) ? (int)((unsigned)(tm + tn + bz) % (unsigned)nk_) : 0;
+#endif
     int64_t oa, ob, coff;
     gemm_batch_offsets(a, bz, oa, ob, coff);
     const bf16* A = a.A + oa;
@@ -285,12 +295,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_glds_kernel(GemmArgs a) 
     }
     auto stage = [&](int kt, int buf) {
         unsigned char* base = smem + buf * STAGE_BYTES;
+        int ks = kt + koff;
+        ks = ks >= nk_ ? ks - nk_ : ks;
 #pragma unroll
         for (int p = 0; p < CA; ++p)
-            __builtin_amdgcn_global_load_lds((glb_void*)(gA[p] + kt * BK), (lds_void*)(base + (wave + WAVES * p) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(gA[p] + ks * BK), (lds_void*)(base + (wave + WAVES * p) * 1024), 16, 0, 0);
 #pragma unroll
         for (int p = 0; p < CB; ++p)
-            __builtin_amdgcn_global_load_lds((glb_void*)(gB[p] + kt * BK), (lds_void*)(base + BM * 128 + (wave + WAVES * p) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(gB[p] + ks * BK), (lds_void*)(base + BM * 128 + (wave + WAVES * p) * 1024), 16, 0, 0);
     };
 
     f32x4 acc[MT][NT];
@@ -682,6 +694,12 @@ static int launch_geglu_persist(const GemmArgs& a, hipStream_t st) {
     return 0;
 }
 #endif
+
+int f16_saturation_gemm(unsigned* count, bool reset) {
+    RALD_HIP(hipMemcpyFromSymbol(count, HIP_SYMBOL(g_f16_sat_gemm), sizeof(unsigned)));
+    if (reset) { const unsigned z = 0; RALD_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_f16_sat_gemm), &z, sizeof(unsigned))); }
+    return 0;
+}
 
 // Host-side shape contract is checked here, before any launch (an out-of-bounds MFMA tile
 // can take the whole node down, so nothing is left to the kernel).

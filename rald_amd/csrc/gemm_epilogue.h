@@ -6,6 +6,10 @@
 
 namespace rald {
 
+// Diagnostic counter of the fp16-slab epilogue (EPI_F16S): lanes that clamped a value (|v| >= 65504 * 64).  One copy per translation unit
+// that includes this header; gemm.hip's is the one EPI_F16S launches write and f16_saturation_gemm() reads.
+static __device__ unsigned g_f16_sat_gemm;
+
 // ---- LDS-staged epilogue (LDS-DMA engine): the MFMA accumulator layout gives every lane 4 columns
 // of 16 different rows, so direct stores touch 32-64 B per row per instruction (measured: 40 % of
 // the FF1 kernel).  Instead each wave transposes one 16-row m-tile at a time through a private LDS
@@ -84,6 +88,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x4 (&acc)[MT][NT], const Ge
                     h4 hv;
                     hv[0] = (_Float16)fminf(fmaxf(o0 * SC, -LIM), LIM); hv[1] = (_Float16)fminf(fmaxf(o1 * SC, -LIM), LIM);
                     hv[2] = (_Float16)fminf(fmaxf(o2 * SC, -LIM), LIM); hv[3] = (_Float16)fminf(fmaxf(o3 * SC, -LIM), LIM);
+                    if (fmaxf(fmaxf(fabsf(o0), fabsf(o1)), fmaxf(fabsf(o2), fabsf(o3))) * SC >= LIM) atomicAdd(&g_f16_sat_gemm, 1u);
                     *reinterpret_cast<h4*>(patch + fr * STRIDE + (16 * j + 4 * fq) * 2) = hv;
                 } else *reinterpret_cast<bf16x4*>(patch + fr * STRIDE + (16 * j + 4 * fq) * 2) = pack4(o0, o1, o2, o3);
             }

@@ -394,10 +394,26 @@ __device__ __forceinline__ void gemm_resid_ln_body(const GemmLnArgs& a) {
         }
         const unsigned voB = (unsigned)(RPP * wave + lr) * (unsigned)(a.ldw * ESZ) + (unsigned)lc * 16u;
         const unsigned stepB = (unsigned)(RPP * WAVES) * (unsigned)(a.ldw * ESZ);     // uniform: bytes between this wave's W pieces
+        // MEASURED, NOT SHIPPED (-DRALD_KOFF builds only): +0.8 % per NFE at B = 64 and B = 128, but an element's fp32 accumulation order then
+        // depends on its tile and on the engine that ran it, so the same sample comes out bit-different in batches of different size (the
+        // bf16 roundings downstream flip) - every kernel here otherwise sums k in ascending 32-chunks whatever the tile shape.
+        // k-steps are walked from a per-tile OFFSET, wrapping around (the sum over k does not care where it starts): launched together,
+        // all 256 workgroups would otherwise ask their XCD's L2 for the SAME 64-KiB k-slice of W at the same moment, 32 requesters per
+        // cache line, at every one of the k-steps - a single-round launch (B = 64: one tile per CU) ran its k-loop 37 % waiting at the
+        // hand-overs, while the same kernel with two rounds of tiles (B = 128, naturally out of step) delivered 1.6 x the FLOP/s.
+        // The offset is a function of the tile's row index alone ((index mod 256) / 8 + index mod 8, mod nk): the 32 tiles that share an XCD
+        // (launch index mod 8 equal) start on different slices, the 4 tiles of a sample with per-sample weights too, and a sub-batch that
+        // starts at a multiple of 64 samples (= 256 tiles) reproduces the whole batch bit for bit.
+#ifndef RALD_KOFF            // off in the shipped build: see below (A/B builds: tools/build_variant.sh koff -DRALD_KOFF)
+        const int koff = 0;
+#else
+        const int koff = RALD_ABLATED(a.nt_io, 8) ? 0 : (int)((unsigned)(((mtile & 255) >> 3) + (mtile & 7)) % (unsigned)nk);
+#endif
+        auto ksrc = [&](int kt) { const int k = kt + koff; return k >= nk ? k - nk : k; };
         auto stage2 = [&](int kt, int buf) {
             unsigned char* base = smem + buf * STAGE_BYTES;
-            const unsigned char* ka = sbA + kt * ROWB;
-            const unsigned char* kb = W0 + kt * ROWB;
+            const unsigned char* ka = sbA + ksrc(kt) * ROWB;
+            const unsigned char* kb = W0 + ksrc(kt) * ROWB;
 #pragma unroll
             for (int p = 0; p < CA; ++p)
                 __builtin_amdgcn_global_load_lds((glb_void*)(ka + voA[p]), (lds_void*)(base + (wave + WAVES * p) * 1024), 16, 0, 0);
@@ -427,8 +443,8 @@ __device__ __forceinline__ void gemm_resid_ln_body(const GemmLnArgs& a) {
         auto substep = [&](int nbuf, int nkk, auto DMA, int kt_next) {
             constexpr bool dma = decltype(DMA)::value;
             unsigned char* dbase = smem + (kt_next & 1) * STAGE_BYTES;
-            const unsigned char* ka = sbA + kt_next * ROWB;
-            const unsigned char* kb = W0 + kt_next * ROWB;
+            const unsigned char* ka = sbA + ksrc(kt_next) * ROWB;
+            const unsigned char* kb = W0 + ksrc(kt_next) * ROWB;
             // (the scalar bases pass through an empty asm: otherwise loop strength reduction turns every piece's address into a 64-bit
             //  lane pointer carried around the loop - the 20 registers this addressing form is here to save)
             auto dmaA = [&](int p) {

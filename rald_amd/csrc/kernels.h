@@ -36,6 +36,9 @@ __device__ __forceinline__ void gemm_batch_offsets(const GemmArgs& a, int bz, in
 }
 #endif
 int gemm_nt(const GemmArgs& a, int epi, hipStream_t st);
+// diagnostic: lanes that clamped an fp16 slab value since the last reset (EPI_F16S here, the per-head slabs in attn_small.hip); blocking
+int f16_saturation_gemm(unsigned* count, bool reset);
+int f16_saturation_attn(unsigned* count, bool reset);
 // EPI_F16S exists on the LDS-DMA engines only: true when gemm_nt would run this shape on one of them (else use EPI_F32)
 inline bool gemm_f16s_ok(int M, int N, int batch) {
     const int64_t w128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * batch, w64 = (int64_t)((M + 63) / 64) * ((N + 63) / 64) * batch;

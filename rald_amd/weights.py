@@ -270,3 +270,36 @@ def make_state_dict(spec: Spec, seed: int = 0) -> "OrderedDict[str, torch.Tensor
 
 def spec_of_state_dict(sd) -> Spec:
     return [(k, tuple(v.shape)) for k, v in sd.items()]
+
+
+# --------------------------------------------------------------------------------------
+# stress variants of the seeded weights (tests/golden/make_golden.py G18 / G19): the plain recipe gives flat softmaxes and
+# O(1) partial sums, which is where the folded fp16 tables and the fp16 x 2^-6 partial-sum slabs are least stressed
+# --------------------------------------------------------------------------------------
+AE_PEAKED_KEYS = ("decoder_cross_attn.fn.to_q.weight", "decoder_cross_attn.fn.to_kv.weight",
+                  "cross_attend_blocks.0.fn.to_q.weight", "cross_attend_blocks.0.fn.to_kv.weight",
+                  "mix_attn_layer.fn.to_q.weight", "mix_attn_layer.fn.to_kv.weight")
+
+
+def stress_ae_state_dict(sd, scale: float = 4.0, embed_bias_offset: float = 0.5, out_bias=None):
+    """Peaked attentions: the q / kv projections of the three point / query attentions times `scale` (logits times scale^2),
+    a constant offset on the PointEmbed bias (a large bias-like term in the folded score tables), and optionally a given
+    `to_outputs.bias` (chosen by the golden script so that the logits straddle 0)."""
+    out = OrderedDict((k, v.clone()) for k, v in sd.items())
+    for k in AE_PEAKED_KEYS:
+        if k in out:
+            out[k] *= scale
+    out["point_embed.mlp.bias"] += embed_bias_offset
+    if out_bias is not None:
+        out["to_outputs.bias"] = torch.tensor([float(out_bias)], dtype=torch.float32)
+    return out
+
+
+def stress_dit_state_dict(sd, scale: float = 8.0):
+    """Large partial sums: every block's attn1 / attn2 `to_out.0.weight` and `ff.net.2.weight` times `scale`, so the per-head and
+    split-K partial sums of the small-batch path (fp16 x 2^-6 slabs) and the residual stream grow by that factor."""
+    out = OrderedDict((k, v.clone()) for k, v in sd.items())
+    for k in out:
+        if k.endswith("to_out.0.weight") or k.endswith("ff.net.2.weight"):
+            out[k] *= scale
+    return out

@@ -179,30 +179,3 @@ def test_fp8_ff_modes_vs_reference_goldens(mode):
     err = rel_l2(edm.sample(cond=cube, batch_seeds=None, cond_type="radar"), g4["sample"])
     print(f"{mode} mode, 18-step sampler rel_l2", err)
     assert err < 7.5e-2
-
-
-@pytest.mark.gpu
-def test_config5_1000_step_sampler_graph_captured_fp8_vs_oracle():
-    """BASELINE config #5 as written: 1000-step sampler (1999 NFE), hipGraph-captured denoise loop, MXFP8 q/k/v.  Depth-2
-    model, B = 1, against the fixture the fp32 CPU oracle produced for the same seeded weights, cube and latents
-    (tests/golden/g13_sample1000_oracle.npz; ~40 s of CPU, so precomputed).  Stated tolerance after 1999 compounding NFEs:
-    1e-2 in bf16 mode (measured 3.2e-3), 4e-2 in fp8 mode (measured 1.7e-2); graph replay must equal eager launches."""
-    import os
-    from conftest import load_golden, rel_l2
-    from rald_amd import config, models_radar_generation as G, weights
-    ref = load_golden("g13_sample1000_oracle.npz")["sample"]
-    m = G.EDMPrecond(n_latents=512, channels=32, depth=2, configs=config.shipped_generation_config())
-    m.load_state_dict(weights.make_state_dict(weights.dit_spec(depth=2), 0), strict=True)
-    m = m.cuda()
-    cube, x = synth.radar_cube(1).cuda(), synth.latents([0]).cuda()
-    outs = {}
-    for mode in ("bf16", "fp8"):
-        m.qkv_dtype = mode
-        for graph in ("1", "0"):
-            os.environ["RALD_GRAPH"] = graph
-            outs[(mode, graph)] = G.edm_sampler(m, x, cube, "radar", num_steps=1000)
-        assert torch.equal(outs[(mode, "1")], outs[(mode, "0")])                 # captured graph == eager launches
-        err = rel_l2(outs[(mode, "1")], ref)
-        print(f"1000-step sampler ({mode} projections) vs fp32 oracle: rel_l2 {err}")
-        assert err < (1e-2 if mode == "bf16" else 4e-2)
-    os.environ.pop("RALD_GRAPH", None)

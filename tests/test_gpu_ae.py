@@ -2,8 +2,8 @@
 captured from the reference, on identical seeded weights / inputs / posterior noise.
 
 Tolerances (bf16 MFMA operands, fp32 accumulate and residual stream; reference is fp32):
-  encode moments / z, rel-L2      <= 2e-2
-  decode logits, rel-L2           <= 3e-2     and occupancy-decision parity (sign of the logit,
+  encode moments / z, rel-L2      <= 8e-3   (measured 3.3e-3 / 3.2e-3 / 2.6e-3; kl 9e-5 -> 3e-4)
+  decode logits, rel-L2           <= 2e-3   (measured 6.5e-4) and occupancy-decision parity (sign of the logit,
   engine_generation.py:229-232) >= 99% on queries whose reference |logit| > 0.05
 """
 import pytest
@@ -42,15 +42,15 @@ def test_full_ae_encode_decode_vs_reference_golden():
     pc = synth.point_cloud(2, 10000).cuda()
     kl, z, mean, logvar = m._handle().encode(pc, g["eps"], want_moments=True)
     print("mean", rel_l2(mean, g["mean"]), "logvar", rel_l2(logvar, g["logvar"]), "z", rel_l2(z, g["z"]), "kl", rel_l2(kl, g["kl"]))
-    assert rel_l2(mean, g["mean"]) < 2e-2 and rel_l2(logvar, g["logvar"]) < 2e-2
-    assert rel_l2(z, g["z"]) < 2e-2 and rel_l2(kl, g["kl"]) < 2e-2
+    assert rel_l2(mean, g["mean"]) < 8e-3 and rel_l2(logvar, g["logvar"]) < 8e-3
+    assert rel_l2(z, g["z"]) < 8e-3 and rel_l2(kl, g["kl"]) < 3e-4
     # decode the REFERENCE latents (isolates decode error from encode error)
     q = synth.queries(2, 4096).cuda()
     logits = m.decode(g["z"].cuda(), q)
     assert logits.shape == (2, 4096, 1)
     ref = g["logits"]
     print("logits", rel_l2(logits, ref), "decision parity", _decision_parity(logits.cpu(), ref))
-    assert rel_l2(logits, ref) < 3e-2
+    assert rel_l2(logits, ref) < 2e-3
     assert _decision_parity(logits.cpu(), ref) > 0.99
 
 
@@ -61,7 +61,7 @@ def test_encode_draws_posterior_noise_like_the_reference():
     m = _ae(dim=512, M=512, latent_dim=32, N=10000)
     torch.manual_seed(99)
     kl, z = m.encode(synth.point_cloud(2, 10000).cuda())
-    assert rel_l2(z, g["z"]) < 2e-2
+    assert rel_l2(z, g["z"]) < 8e-3
 
 
 def test_tiny_ae_forward_vs_reference_golden():
@@ -73,8 +73,8 @@ def test_tiny_ae_forward_vs_reference_golden():
     out = m(synth.point_cloud(2, 1000).cuda(), synth.queries(2, 1000).cuda())
     print("tiny logits", rel_l2(out["logits"], g["logits"]), "kl", rel_l2(out["kl"], g["kl"]))
     assert out["logits"].shape == (2, 1000)
-    assert rel_l2(out["kl"], g["kl"]) < 2e-2
-    assert rel_l2(out["logits"], g["logits"]) < 4e-2
+    assert rel_l2(out["kl"], g["kl"]) < 5e-4                           # measured 1.8e-4
+    assert rel_l2(out["logits"], g["logits"]) < 2e-2                   # measured 7.9e-3
 
 
 def test_decode_many_queries_chunked_and_ragged():

@@ -36,7 +36,8 @@ def test_two_stream_nfe_is_bit_identical_to_one_stream_and_to_two_half_batches()
     h.set_sigmas([0.7])
     cache = h.encode_cond_tokens(cond)
     from rald_amd._lib import lib
-    assert lib().rald_dit_two_stream_min_batch(h._h) == 128          # the shipped default
+    assert lib().rald_dit_two_stream_min_batch(h._h) == 256          # the shipped default (B = 128 gains nothing from the split)
+    h.set_two_stream_min_batch(128)
     split = h.denoise(x, cache, 0)
     split2 = h.denoise(x, cache, 0)
     assert torch.equal(split, split2)                                 # run to run
@@ -63,9 +64,10 @@ def test_two_stream_sampler_matches_unsplit_sampler():
     from rald_amd import synth
     m = _transformer(2)
     h = m._handle(512, 64)
-    B = 130                                                           # ragged: 72 + 58
+    B = 130                                                           # ragged: 64 + 66
     lat = synth.latents(range(B)).cuda()
     cache = h.encode_cond_tokens(synth.cond_tokens(B).cuda())
+    h.set_two_stream_min_batch(128)
     s1 = h.sample(lat, cache, 4)
     h.set_two_stream_min_batch(0)
     s0 = h.sample(lat, cache, 4)

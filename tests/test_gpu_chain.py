@@ -5,7 +5,7 @@ tensors freed and re-allocated at the same address between frames, weights chang
 hipGraphs after a workspace reallocation, and the bench configuration (B = 64) at model level.
 
 Stated tolerances (bf16 MFMA operands, fp32 accumulation and residual stream; the reference is fp32):
-  sample -> decode logits, rel-L2        <= 3e-2 (bf16 mode), <= 8e-2 (MXFP8 q/k/v), <= 1e-1 (MXFP8 q/k/v + GEGLU)
+  sample -> decode logits, rel-L2        <= 2.5e-2 (bf16 mode: measured 9.7e-3), <= 1.4e-2 (MXFP8 q/k/v: 5.4e-3), <= 4.3e-2 (MXFP8 q/k/v + GEGLU: 1.7e-2)
   occupancy decision parity (logit > 0)   >= 99 % - all logits of the seeded random weights are positive, so the SAME
                                           number is also reported against the reference's median logit (half the
                                           queries on each side of the threshold), excluding |logit - thr| < 0.1 sigma
@@ -78,7 +78,7 @@ def test_three_frames_with_recycled_addresses_vs_reference_golden(vae):
         again = vae.decode(sampled_tokens, qf[:, :512]).squeeze(-1)                                        # :275 - same latents, memo hit
         es, el = rel_l2(sampled_tokens[0], g["frame_samples"][i]), rel_l2(outputs[0], g["frame_logits"][i])
         print(f"frame {i}: sample rel_l2 {es:.2e}, logits rel_l2 {el:.2e}")
-        assert es < 5e-2 and el < 3e-2
+        assert es < 9e-3 and el < 2.5e-2                                 # measured <= 3.4e-3 / <= 9.7e-3
         assert torch.equal(again[0], outputs[0, :512])
     # the hazard was really exercised: the allocator handed a dead frame's block to a later frame holding a DIFFERENT cube (not
     # necessarily to the very next one: the memo entry keeps one frame's tensor alive until the next frame replaces it - that
@@ -132,7 +132,7 @@ def test_evaluate_sharded_three_frames_equals_per_frame_results(vae):
         assert torch.equal(seen[i], per_frame[i]), f"frame {i} differs from its stand-alone result"
 
 
-@pytest.mark.parametrize("mode,tol", [("bf16", 3e-2), ("fp8", 8e-2), ("fp8_ff1", 1e-1)])
+@pytest.mark.parametrize("mode,tol", [("bf16", 2.5e-2), ("fp8", 1.4e-2), ("fp8_ff1", 4.3e-2)])
 def test_config4_sample_and_decode_full_depth_vs_reference_golden(vae, mode, tol):
     """engine_generation.sample_and_decode = the chain :195 -> :204 -> :229-232 at the shipped depth (24 blocks, 18 Heun
     steps, 24-layer decode) against the reference's chain output; the third number of SURVEY.md section 8d."""
@@ -236,8 +236,8 @@ def test_learnable_query_autoencoder_vs_reference_golden():
     m = m.cuda()
     kl, z, mean, logvar = m._handle().encode(synth.point_cloud(2, 10000).cuda(), g["eps"], want_moments=True)
     print("learnable: mean", rel_l2(mean, g["mean"]), "logvar", rel_l2(logvar, g["logvar"]), "z", rel_l2(z, g["z"]), "kl", rel_l2(kl, g["kl"]))
-    assert rel_l2(mean, g["mean"]) < 2e-2 and rel_l2(logvar, g["logvar"]) < 2e-2
-    assert rel_l2(z, g["z"]) < 2e-2 and rel_l2(kl, g["kl"]) < 2e-2
+    assert rel_l2(mean, g["mean"]) < 8e-3 and rel_l2(logvar, g["logvar"]) < 8e-3        # measured 3.3e-3
+    assert rel_l2(z, g["z"]) < 8e-3 and rel_l2(kl, g["kl"]) < 3e-4                       # measured 2.7e-3 / 1.2e-4
     logits = m.decode(g["z"].cuda(), synth.queries(2, 4096).cuda())
     print("learnable: logits", rel_l2(logits, g["logits"]))
-    assert rel_l2(logits, g["logits"]) < 3e-2
+    assert rel_l2(logits, g["logits"]) < 2.5e-3                         # measured 9.6e-4

@@ -5,7 +5,7 @@ captured from the reference.
 Tolerances (bf16 MFMA operands, fp32 accumulate, fp32 residual stream; the reference is fp32,
 so these are this build's stated bounds - SURVEY.md §8d):
   one NFE, rel-L2 of F_x / D_x            <= 1.5e-2
-  18-step sampler (35 compounding NFEs)   <= 5e-2
+  18-step sampler (35 compounding NFEs)   <= 1.2e-2   (measured 4.5e-3; bounds are <= 2.5 x the measured values)
 """
 import pytest
 import torch
@@ -22,7 +22,7 @@ def _inference_mode():
     with torch.no_grad():
         yield
 TOL_NFE = 1.5e-2
-TOL_SAMPLE = 5e-2
+TOL_SAMPLE = 1.2e-2
 
 
 def _transformer(depth, context_dim=None, seed=0, seeded_prefix=""):

@@ -5,8 +5,8 @@ reference (identical seeded weights, cube and per-sample CPU-generator noise).
 Tolerances (bf16 MFMA operands / fp32 accumulate; reference fp32):
   condition tokens (23 conv layers + GroupNorm)   rel-L2 <= 1.5e-2
   one NFE D_x                                     rel-L2 <= 1.5e-2
-  18-step sampler (35 compounding NFEs)           rel-L2 <= 5e-2
-  100-step sampler, depth-2 model (199 NFEs)      rel-L2 <= 5e-2
+  18-step sampler (35 compounding NFEs)           rel-L2 <= 1.2e-2   (measured 4.5e-3)
+  100-step sampler, depth-2 model (199 NFEs)      rel-L2 <= 8e-3     (measured 3.1e-3)
 """
 import pytest
 import torch
@@ -65,7 +65,7 @@ def test_sample_18_steps_vs_reference_golden(edm24):
     err = rel_l2(s, g["sample"])
     print("18-step sampler rel_l2", err)
     assert s.shape == (2, 512, 32)
-    assert err < 5e-2
+    assert err < 1.2e-2
 
 
 def test_depth2_per_sample_sigma_and_100_step_sampler_vs_reference_golden():
@@ -80,7 +80,7 @@ def test_depth2_per_sample_sigma_and_100_step_sampler_vs_reference_golden():
     assert rel_l2(d, g["d_x"]) < 1.5e-2
     s100 = G.edm_sampler(m, synth.latents([0, 1]).cuda(), cube, "radar", num_steps=100)
     print("100-step sampler rel_l2", rel_l2(s100, g["sample100"]))
-    assert rel_l2(s100, g["sample100"]) < 5e-2
+    assert rel_l2(s100, g["sample100"]) < 8e-3
 
 
 def test_sample_concurrent_equals_sequential_sampling():

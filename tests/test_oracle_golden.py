@@ -195,3 +195,42 @@ def test_g16_edm_loss_gradient_norm(sd_d2):
     assert abs(total - float(g["grad_norm"])) < 1e-4 * float(g["grad_norm"])
     for name, ref in zip(g["group_names"], g["group_norms"]):
         assert abs(sq[str(name)] ** 0.5 - float(ref)) < 1e-4 * float(ref) + 1e-7
+
+
+@pytest.mark.parametrize("tag", ["plain", "peaked"])
+def test_g18_autoencoder_on_structured_cloud(tag):
+    """Round 3 stress vectors: structured cloud (planes, exact duplicates, +-1 faces), plain and peaked attentions."""
+    g = load_golden("g18_ae_stress.npz")
+    sd = weights.make_state_dict(weights.ae_spec(), seed=0)
+    if tag == "peaked":
+        sd = weights.stress_ae_state_dict(sd, out_bias=float(g["peaked_out_bias"]))
+    kl, z, mean, logvar = O.ae_encode(sd, synth.structured_cloud(2, 10000), g["eps"])
+    assert rel_l2(mean, g[f"{tag}_mean"]) < TOL and rel_l2(logvar, g[f"{tag}_logvar"]) < TOL
+    assert rel_l2(z, g[f"{tag}_z"]) < TOL and rel_l2(kl, g[f"{tag}_kl"]) < TOL
+    logits = O.ae_decode(sd, g[f"{tag}_z"], synth.structured_queries(2, 4096), depth=24).squeeze(-1)
+    ref = g[f"{tag}_logits"]
+    assert float((logits - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max()))      # (peaked logits straddle 0: absolute bound)
+    if tag == "peaked":
+        assert 0.4 < float((ref > 0).float().mean()) < 0.6
+
+
+def test_g19_denoiser_with_scaled_output_projections():
+    g = load_golden("g19_dit_stress.npz")
+    sd = weights.stress_dit_state_dict(weights.make_state_dict(weights.dit_spec(depth=2, with_radar=False, prefix=""), 0))
+    cond = synth.cond_tokens(2, seed=781)
+    for sigma in (80.0, 1.0):
+        x = synth.latents([5, 6]) * max(sigma, 1.0)
+        s = torch.tensor(sigma)
+        c_skip, c_out, c_in, c_noise = 1 / (s ** 2 + 1), s / (s ** 2 + 1).sqrt(), 1 / (1 + s ** 2).sqrt(), s.log() / 4
+        for B in (1, 2):
+            F = O.latent_transformer(sd, c_in * x[:B], c_noise.flatten(), cond[:B], depth=2, prefix="")
+            assert rel_l2(c_skip * x[:B] + c_out * F, g[f"d_sigma{int(sigma)}_B{B}"]) < TOL
+
+
+@pytest.mark.skipif(os.environ.get("RALD_LONG_TESTS", "0") != "1", reason="~2 min of CPU: RALD_LONG_TESTS=1 (the GPU tests compare the HIP path with these reference vectors directly)")
+def test_g13_g17_long_sampler_horizons():
+    for fname, depth, steps in (("g13_sample1000.npz", 2, 1000), ("g17_sample100_depth24.npz", 24, 100)):
+        sd = weights.make_state_dict(weights.dit_spec(depth=depth), 0)
+        cond = O.process_radar_cond(sd, synth.radar_cube(1))
+        s = O.edm_sampler(lambda xx, ss: O.edm_precond(sd, xx, ss, cond, depth=depth), synth.latents([0]), num_steps=steps)
+        assert rel_l2(s, load_golden(fname)["sample"]) < 1e-4
