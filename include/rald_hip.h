@@ -34,6 +34,10 @@ int rald_build_flags(void);
  * reset.  The small-batch paths (<= 2 samples) pass per-head / split-K partial sums between kernels as fp16 x 2^-6, saturating at
  * +-4.19e6; a non-zero count means a result was clipped.  Returns -1 on a HIP error. */
 int64_t rald_debug_f16_saturation_count(int32_t reset);
+/* Diagnostic: one launch that leaves all 160 KiB of LDS of every CU filled with NaN patterns (0x7fc07fc0).  LDS is not cleared
+ * between workgroups, so a kernel that reads a word it never wrote is only wrong when something else ran on that CU before it -
+ * i.e. under concurrent streams.  The test suite poisons the LDS and requires bit-identical results. */
+int rald_debug_poison_lds(void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Denoiser: EDMPrecond + LatentArrayTransformer  (model/models_radar_generation.py:171-233,
@@ -263,7 +267,6 @@ int rald_radar_cube_prepare(const float* raw, int32_t batch, int32_t R, int32_t 
 int rald_op_gemm_nt(const void* A, int64_t lda, int64_t strideA, const void* B, int64_t ldb, int64_t strideB,
                     void* C, int64_t ldc, int64_t strideC, const float* bias, int32_t M, int32_t N, int32_t K,
                     int32_t batch, float alpha, int32_t epilogue, void* stream);
-/* out_bf16 = LayerNorm(x_f32[M][D]) * (add_one + g[row/rows_per_group*gstride + c]) + b[...] */
 /* rald_op_gemm_nt with an inner batch (attention heads): grid z = batch * batch2, operand offset =
  * b1 * stride + b2 * stride2 */
 int rald_op_gemm_nt2(const void* A, int64_t lda, int64_t strideA, int64_t strideA2, const void* B, int64_t ldb, int64_t strideB, int64_t strideB2,
@@ -271,7 +274,6 @@ int rald_op_gemm_nt2(const void* A, int64_t lda, int64_t strideA, int64_t stride
                      int32_t batch2, float alpha, int32_t epilogue, void* stream);
 /* Backward building blocks of the transformer block (what autograd derives for
  * models_radar_generation.py:35-169).  dX = dY.W and dW = dY^T.X run on rald_op_gemm_nt with transposed operands. */
-/* in [batch][batch2][rows][cols] (f32 or bf16) -> out [batch][batch2][cols][rows] bf16 */
 /* Weight gradient of a Linear without transposed copies (rald_amd/csrc/gemm_tn.hip): C[n1][n2] += sum_m A[m][n1] B[m][n2] for row-major bf16
  * A [M, N1] (= dY) and B [M, N2] (= X), fp32 C accumulated into with atomics; colsum (nullable) [N1] += column sums of A (the bias gradient).
  * N1, N2, lda, ldb multiples of 8. */
@@ -285,6 +287,7 @@ int rald_op_conv3d_wgrad(const void* dy_bf16, const void* x_bf16, float* dW, flo
 /* conv_in (one input channel) weight gradient, first half: the 27-neighbourhood of channel 0 of cube [B][D][H][W][cube_ch] fp32 per voxel as one
  * bf16 row of 32 (taps kd*9 + kh*3 + kw, zero outside the volume, 5 zero pads); dW = rald_op_gemm_tn(dy, patches). */
 int rald_op_patches27(const float* cube, int32_t cube_ch, void* out_bf16, int32_t B, int32_t D, int32_t H, int32_t W, void* stream);
+/* in [batch][batch2][rows][cols] (f32 or bf16) -> out [batch][batch2][cols][rows] bf16 */
 int rald_op_transpose(const void* in, int32_t in_is_bf16, int64_t ld_in, int64_t stride_in, int64_t stride_in2, void* out_bf16, int64_t ld_out,
                       int64_t stride_out, int64_t stride_out2, int32_t rows, int32_t cols, int32_t batch, int32_t batch2, void* stream);
 /* AdaLayerNorm :119-131 (add_one = 1) / LayerNorm (add_one = 0, scale = weight) backward, D = 512:
@@ -403,14 +406,13 @@ int rald_op_quantize_mx8(const void* in, int32_t in_is_bf16, int64_t ld_in, void
 /* rald_op_layernorm with an MXFP8 result (D = 512) */
 int rald_op_layernorm_mx8(const float* x, void* out_e4m3, void* out_scales_e8m0, int64_t M, int32_t D, const float* g, const float* b,
                           int64_t gstride, int32_t rows_per_group, float add_one, float eps, void* stream);
+/* out_bf16 = LayerNorm(x_f32[M][D]) * (add_one + g[row/rows_per_group*gstride + c]) + b[...] */
 int rald_op_layernorm(const float* x, void* out_bf16, int32_t M, int32_t D, const float* g, const float* b,
                       int64_t gstride, int32_t rows_per_group, float add_one, float eps, void* stream);
 /* multi-head attention, head dim 64; Q[b][i][h*64+d], K[b][j][h*64+d], Vt[b][h*64+d][j] bf16 */
 int rald_op_attention(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK,
                       const void* Vt, int64_t ldvt, int64_t strideVt, void* O, int64_t ldo, int64_t strideO,
                       int32_t nq, int32_t nk, int32_t k_rows, int32_t heads, int32_t batch, float scale, void* stream);
-/* fused residual GEMM + next LayerNorm (N = 512): x[M][512] += A[M][K].W[512][K]^T + bias (fp32, in place);
- * h_bf16 = LayerNorm(x) * (add_one + g[row/rows_per_group*gstride + c]) + b[...] */
 /* rald_op_attention with the keys split over `ksplit` workgroups per query block (few queries x many keys, e.g. 512
  * latents x 10 000 points at batch 1): partial results go through `scratch` (rald_op_attention_split_scratch_bytes)
  * and a combine pass.  ksplit <= 0 picks a value from the shape. */
@@ -423,6 +425,8 @@ int rald_op_attention_split(const void* Q, int64_t ldq, int64_t strideQ, const v
 int rald_op_attention_vrow(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK, const void* V, int64_t ldv,
                            int64_t strideV, void* O, int64_t ldo, int64_t strideO, int32_t nq, int32_t nk, int32_t heads, int32_t batch, float scale,
                            void* stream);
+/* fused residual GEMM + next LayerNorm (N = 512): x[M][512] += A[M][K].W[512][K]^T + bias (fp32, in place);
+ * h_bf16 = LayerNorm(x) * (add_one + g[row/rows_per_group*gstride + c]) + b[...] */
 int rald_op_gemm_resid_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* x, void* h_bf16,
                           const float* g, const float* b, int64_t gstride, int32_t rows_per_group, float add_one, float eps,
                           int32_t M, int32_t K, void* stream);

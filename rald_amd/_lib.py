@@ -43,6 +43,7 @@ SIGNATURES = {
     "rald_dit_load_weight": (c_int, [c_void_p, c_char_p, c_void_p, c_i64]),
     "rald_dit_finalize": (c_int, [c_void_p]),
     "rald_debug_f16_saturation_count": (c_i64, [c_int]),
+    "rald_debug_poison_lds": (c_int, [c_void_p]),
     "rald_dit_reserve": (c_int, [c_void_p, c_int]),
     "rald_dit_workspace_generation": (c_i64, [c_void_p]),
     "rald_dit_set_two_stream_min_batch": (c_int, [c_void_p, c_int]),

@@ -29,6 +29,8 @@ int64_t rald_debug_f16_saturation_count(int32_t reset) {
     return (int64_t)a + (int64_t)b;
 }
 
+int rald_debug_poison_lds(void* stream) { return poison_lds((hipStream_t)stream); }
+
 void rald_dit_default_config(rald_dit_config* c) {
     c->n_latents = 512; c->channels = 32; c->depth = 24; c->n_heads = 8; c->d_head = 64; c->t_channels = 256;
     c->context_dim = 512; c->n_cond_tokens = 64; c->with_radar_enc = 1; c->enc_hidden_ch = 64; c->enc_radar_ch = 16;

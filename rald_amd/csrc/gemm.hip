@@ -236,7 +236,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_glds_kernel(GemmArgs a) 
 #ifdef RALD_GEMM_STAMPS
     if (threadIdx.x == 0) { g_gemm_stamps[lin & 8191][6] = __builtin_amdgcn_s_getreg(63492); g_gemm_stamps[lin & 8191][7] = __builtin_amdgcn_s_getreg(63508); }
 #endif
-    const int GN = RALD_ABLATED(a.ablate, 128) ? 16 : 8;       // probe builds: bit 128 = strips of 16 n-tiles (A panels fetched once at N = 4096)
+#ifdef RALD_GN16               // A/B builds (tools/build_variant.sh): strips of 16 n-tiles (A panels fetched once at N = 4096)
+    const int GN = 16;
+#else
+    const int GN = RALD_ABLATED(a.ablate, 128) ? 16 : 8;       // probe builds: bit 128 = strips of 16 n-tiles
+#endif
     int tm, tn;
     if (ntn % GN == 0) {
         const int strip = tile / (ntm * GN), within = tile % (ntm * GN);

@@ -147,6 +147,8 @@ int skinny_linear(const float* in, const float* W, const float* bias, float* out
 // pe[s][0:128] = cos(c_noise[s]*f_i), pe[s][128:256] = sin(..)   (PositionalEmbedding)
 int positional_embedding(const float* c_noise, float* pe, int S, int channels, hipStream_t st);
 int cast_f32_bf16(const float* in, bf16* out, int64_t n, hipStream_t st);
+// diagnostic: fills the LDS of every CU with NaN patterns (see small.hip)
+int poison_lds(hipStream_t st);
 // dst_bf16[map(r)][c] = src_f32[r][c] ; map==nullptr -> identity; ld_dst >= cols (pad zero-filled by caller)
 int pack_rows_bf16(const float* src, bf16* dst, int rows, int cols, int64_t ld_dst, const int* rowmap, hipStream_t st);
 int scale_f32(const float* in, float* out, float s, int64_t n, hipStream_t st);

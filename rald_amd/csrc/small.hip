@@ -145,4 +145,29 @@ int heun_correct(const float* x_hat, const float* x_euler, const float* denoised
     return 0;
 }
 
+
+// ---- diagnostic: leave every CU's LDS full of NaN patterns ---------------------------------------------------------------------------
+// LDS is not cleared between workgroups.  A kernel that reads an LDS word it never wrote gets whatever the previous workgroup on that
+// CU left there: zeros or its own old values when it runs alone back to back (so the bug stays invisible), another kernel's data
+// when streams share the chip - the one class of defect that shows up ONLY under concurrency without being a race.  The poison
+// test (tests/test_gpu_boundary.py) fills all 160 KiB of every CU with 0x7fc07fc0 (a NaN as fp32, bf16 and fp16) and then requires
+// bit-identical results from the product kernels.
+__global__ __launch_bounds__(1024) void poison_lds_kernel(int words) {
+    extern __shared__ unsigned lds_words[];
+    for (int i = threadIdx.x; i < words; i += 1024) lds_words[i] = 0x7fc07fc0u;
+    __syncthreads();
+    if (lds_words[(threadIdx.x * 37) % words] != 0x7fc07fc0u) __builtin_trap();     // (keeps the stores alive)
+}
+int poison_lds(hipStream_t st) {
+    constexpr int bytes = 160 * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        RALD_HIP(hipFuncSetAttribute((const void*)poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(4096), dim3(1024), bytes, st, bytes / 4);      // 16 workgroups per CU in turn: every CU is hit
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace rald

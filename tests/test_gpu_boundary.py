@@ -139,3 +139,43 @@ def test_decoder_context_of_another_batch_is_refused():
     q2 = synth.queries(2, 256).cuda()
     ref = h.decode_queries(ctx2, q2)
     assert torch.equal(h.decode_queries(ctx2.clone(), q2), ref)
+
+
+def test_results_do_not_depend_on_what_the_lds_held_before():
+    """VERDICT r02 weak #4 / ADVICE: a dropped kernel variant gave different results only when other streams shared the chip.  LDS
+    is not cleared between workgroups: a read of a never-written LDS word is invisible back to back and wrong under concurrency.
+    Every product path must give bit-identical (and finite) results after all LDS of the chip has been filled with NaN patterns."""
+    from rald_amd import bench_ae, config, models_radar_generation as G, synth, weights
+    from rald_amd._lib import check, lib
+    st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    m = G.EDMPrecond(n_latents=512, channels=32, depth=2, configs=config.shipped_generation_config())
+    m.load_state_dict(weights.make_state_dict(weights.dit_spec(depth=2), 0), strict=True)
+    m = m.cuda()
+    vae = bench_ae.build_ae()
+    h = m._handle()
+    cases = {}
+    for B in (1, 2, 8, 64):                                          # small-batch fused kernels, mid engines, the large-batch engines
+        x = synth.latents(range(B)).cuda()
+        cond = synth.cond_tokens(B, seed=5).cuda()
+
+        def nfe(x=x, cond=cond):
+            h.set_sigmas([1.3])
+            return h.denoise(x, h.encode_cond_tokens(cond), 0)
+        cases[f"nfe_B{B}"] = nfe
+    cube = synth.radar_cube(1).cuda()
+    cases["cond_encode"] = lambda: h.encode_cond(cube)[0]
+    cases["sample_B1"] = lambda: h.sample(synth.latents([3]).cuda(), h.encode_cond(cube)[1], 3, use_graph=False)
+    pc, eps, q = synth.structured_cloud(1, 10000).cuda(), synth.normal([1, 512, 32], 3), synth.structured_queries(1, 5000).cuda()
+    ah = vae._handle()
+    cases["ae_encode"] = lambda: ah.encode(pc, eps)[1]
+    z = synth.normal([2, 512, 32], 9).cuda()
+    cases["ae_decode"] = lambda: ah.decode_queries(ah.decode_latents(z[:1].contiguous(), use_graph=False), q)
+    cases["ae_decode_B2"] = lambda: ah.decode_queries(ah.decode_latents(z, use_graph=False), torch.cat([q, q]))
+    for name, fn in cases.items():
+        ref = fn()
+        torch.cuda.synchronize()
+        check(lib().rald_debug_poison_lds(st()))
+        out = fn()
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all(), name
+        assert torch.equal(out, ref), name
