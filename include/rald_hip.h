@@ -179,6 +179,12 @@ int rald_radar_load_weight(rald_radar* h, const char* name, const float* data, i
 int rald_radar_finalize(rald_radar* h);
 /* cube [B,R,A,E,in_channels] -> z [B,R/16,A/16,E/16,embed_dim]  (= _encode's permuted output) */
 int rald_radar_encode(rald_radar* h, const float* cube, int32_t batch, float* out_z, void* stream);
+/* Decoder half (Decoder.forward :333-359, RadarAutoencoder.decode / forward :386-406): keys below "decoder." are loaded with
+ * rald_radar_load_decoder_weight (optional: the generation path only encodes; once one is loaded rald_radar_finalize wants all).
+ * z [B, R/16, A/16, E/16, embed_dim] (the layout rald_radar_encode returns) -> out_pred4 [B, R, A, E, 4] fp32: channels 0-1 are the
+ * reconstruction (RadarAutoencoder.forward's 'pred' is out_pred4[..., :2]), channels 2-3 are zero padding of the convolution kernel. */
+int rald_radar_load_decoder_weight(rald_radar* h, const char* name, const float* data, int64_t nelem);
+int rald_radar_decode(rald_radar* h, const float* z, int32_t batch, float* out_pred4, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Decode post-processing on the device (the host tail of engine_generation.evaluate, :229-243 and

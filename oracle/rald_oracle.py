@@ -173,6 +173,28 @@ def radar_encoder(sd: SD, x, prefix: str = "radar_enc.", n_levels: int = 5, n_re
     return _conv(sd, prefix + "conv_out", h)
 
 
+def radar_decoder(sd: SD, z, prefix: str = "decoder.", n_levels: int = 5, n_res: int = 2):
+    """Decoder.forward :333-359 (attn_resolutions=() : only mid.attn_1).  z [B,z,R/16,A/16,E/16] -> [B,out_ch,R,A,E]."""
+    h = _conv(sd, prefix + "conv_in", z)
+    h = _resblock(sd, prefix + "mid.block_1", h)
+    h = _attnblock(sd, prefix + "mid.attn_1", h)
+    h = _resblock(sd, prefix + "mid.block_2", h)
+    for lvl in reversed(range(n_levels)):
+        for b in range(n_res + 1):
+            h = _resblock(sd, f"{prefix}up.{lvl}.block.{b}", h)
+        if lvl != 0:
+            # Upsample :18-27 - nearest-neighbour x2, then conv k3
+            h = _conv(sd, f"{prefix}up.{lvl}.upsample.conv", F.interpolate(h, scale_factor=2.0, mode="nearest"))
+    h = _swish(_gn(sd, prefix + "norm_out", h))
+    return _conv(sd, prefix + "conv_out", h)
+
+
+def radar_autoencoder_forward(sd: SD, cube: torch.Tensor):
+    """RadarAutoencoder.forward :395-406: cube [B,R,A,E,2] -> {'pred': [B,R,A,E,2], 'latent': [B,z,R/16,A/16,E/16]}."""
+    z = radar_encoder(sd, cube.permute(0, 4, 1, 2, 3), prefix="encoder.")
+    return {"pred": radar_decoder(sd, z).permute(0, 2, 3, 4, 1), "latent": z}
+
+
 def process_radar_cond(sd: SD, cube: torch.Tensor, unfreeze_radar_enc: bool = True):
     """EDMPrecond.process_radar_cond :363-407.  cube [B,R,A,E,2] -> tokens [B,R'A'E',C]
     (r-major, then a, then e)."""

@@ -71,6 +71,8 @@ SIGNATURES = {
     "rald_radar_load_weight": (c_int, [c_void_p, c_char_p, c_void_p, c_i64]),
     "rald_radar_finalize": (c_int, [c_void_p]),
     "rald_radar_encode": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "rald_radar_load_decoder_weight": (c_int, [c_void_p, C.c_char_p, c_void_p, c_i64]),
+    "rald_radar_decode": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "rald_post_scratch_bytes": (c_i64, [c_i64]),
     "rald_post_occupied_points": (c_int, [c_void_p, c_void_p, c_i64, C.POINTER(C.c_double), c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p]),

@@ -136,10 +136,12 @@ def _edm24():
 
 
 def config4_leg(rank: int, world: int, frames: int = 4) -> dict:
-    """BASELINE config #4, the reference's evaluate chain at its own eval_batch_size = 1 (engine_generation.py:173-300): per
-    frame radar cube -> EDMPrecond.sample (18 Heun steps, condition encoded once) -> vae.decode on 1.2 M query points ->
-    refine pass on 500 k queries (the latent stack runs once per frame).  Each rank processes its own `frames` frames; no
-    collective.  Returns seconds for this rank's frames and the number of frames over all ranks."""
+    """BASELINE config #4, the reference's evaluate chain (engine_generation.py:173-300): per frame radar cube ->
+    EDMPrecond.sample (18 Heun steps, condition encoded once) -> vae.decode on 1.2 M query points -> refine pass on 500 k
+    queries (the latent stack runs once per frame).  Headline of the leg: the reference's own eval_batch_size = 1, `frames`
+    frames per rank, no collective.  The same chain at eval batches of 8 and 64 frames (the loop of `evaluate_sharded`; the
+    query sets are decoded per frame against the batch's contexts) is reported beside it: the reference's batch size is a
+    YAML value, and batching is where the chip fills up."""
     from . import bench_ae, engine_generation as E
     m, vae = _edm24(), bench_ae.build_ae()
     q1, q2 = synth.queries(1, 1200000, seed=11).cuda(), synth.queries(1, 500000, seed=12).cuda()
@@ -152,9 +154,29 @@ def config4_leg(rank: int, world: int, frames: int = 4) -> dict:
     n_occ = int(out["occupied"][0].sum())
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"seconds": dt, "units_all_ranks": frames * world, "unit": "frames/s", "frames_per_rank": frames, "eval_batch_size": 1,
-            "queries_per_frame": 1700000, "ms_per_frame_this_rank": dt / frames * 1e3, "occupied_last_frame": n_occ,
-            "workload": "configs[3]: radar cube -> 18-step sample -> decode 1.2 M + 500 k queries, batch-sharded, no collective"}
+    res = {"seconds": dt, "units_all_ranks": frames * world, "unit": "frames/s", "frames_per_rank": frames, "eval_batch_size": 1,
+           "queries_per_frame": 1700000, "ms_per_frame_this_rank": dt / frames * 1e3, "occupied_last_frame": n_occ,
+           "workload": "configs[3]: radar cube -> 18-step sample -> decode 1.2 M + 500 k queries, batch-sharded, no collective"}
+    # batched evaluation: B frames sampled together, both query sets decoded for the whole batch (latent stack at batch B)
+    for B in (8, 64):
+        try:
+            cube = synth.radar_cube(B, seed=5000 + rank).cuda()
+            seeds = torch.arange(rank * B, rank * B + B)
+
+            qb1, qb2 = q1.expand(B, -1, -1), q2.expand(B, -1, -1)
+
+            def batch():
+                return E.sample_and_decode(m, vae, cube, [qb1, qb2], batch_seeds=seeds)
+            batch()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            batch()
+            torch.cuda.synchronize()
+            dtb = time.perf_counter() - t0
+            res[f"eval_batch_{B}"] = {"ms_per_frame_this_rank": dtb / B * 1e3, "frames_per_s_this_rank": B / dtb}
+        except Exception as e:                    # secondary numbers never invalidate the leg
+            res[f"eval_batch_{B}"] = {"error": repr(e)}
+    return res
 
 
 def ddp_step_leg(rank: int, world: int, B: int = 8, steps: int = 3) -> dict:

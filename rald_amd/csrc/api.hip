@@ -167,12 +167,13 @@ int rald_op_ae_decode_tables(int32_t dim, const float* wq, const float* wk, cons
 }
 
 // ---- standalone radar-spectrum encoder (RadarAutoencoder.encoder) -------------------------------
-struct rald_radar { DeviceArena arena; Stager stager; RadarEncoder enc; int R, A, E, cin, zc; };
+struct rald_radar { DeviceArena arena; Stager stager; RadarEncoder enc, dec; int R, A, E, cin, zc; bool dec_touched = false; };
 int rald_radar_create(int32_t basic_channel, int32_t embed_dim, int32_t in_channels, int32_t R, int32_t A, int32_t E, rald_radar** out) {
     RALD_CHECK(out, "rald_radar_create: null argument");
     rald_radar* h = new rald_radar();
     h->R = R; h->A = A; h->E = E; h->cin = in_channels; h->zc = embed_dim;
     int rc = h->enc.create(basic_channel, embed_dim, R, A, E, 512, &h->arena, in_channels);
+    if (!rc) rc = h->dec.create_decoder(basic_channel, embed_dim, 2, R, A, E, &h->arena);
     if (rc) { delete h; return rc; }
     *out = h;
     return 0;
@@ -186,11 +187,24 @@ int rald_radar_load_weight(rald_radar* h, const char* name, const float* data, i
     RALD_CHECK(h && name && data, "rald_radar_load_weight: null argument");
     return h->enc.load_weight(name, data, nelem, h->stager);
 }
+int rald_radar_load_decoder_weight(rald_radar* h, const char* name, const float* data, int64_t nelem) {
+    RALD_CHECK(h && name && data, "rald_radar_load_decoder_weight: null argument");
+    h->dec_touched = true;
+    return h->dec.load_weight(name, data, nelem, h->stager);
+}
 int rald_radar_finalize(rald_radar* h) {
     RALD_CHECK(h, "null handle");
     std::string missing;
     RALD_CHECK(h->enc.all_loaded(&missing), "radar encoder: missing key '" + missing + "' (strict load)");
+    // the decoder is optional (the generation path only encodes); once one of its tensors was loaded, all must be
+    RALD_CHECK(!h->dec_touched || h->dec.all_loaded(&missing), "radar decoder: missing key '" + missing + "' (strict load)");
     return 0;
+}
+int rald_radar_decode(rald_radar* h, const float* z, int32_t batch, float* out_pred4, void* stream) {
+    RALD_CHECK(h && z && out_pred4 && batch >= 1, "rald_radar_decode: bad argument");
+    std::string missing;
+    RALD_CHECK(h->dec.all_loaded(&missing), "radar decoder: weights not loaded ('" + missing + "')");
+    return h->dec.decode(z, batch, out_pred4, (hipStream_t)stream);
 }
 int rald_radar_encode(rald_radar* h, const float* cube, int32_t batch, float* out_z, void* stream) {
     RALD_CHECK(h && cube && out_z && batch >= 1, "rald_radar_encode: bad argument");

@@ -60,6 +60,10 @@ struct RadarEncoder {
     int tokens(const float* cube, int B, float** tokens, hipStream_t st);
     // cube channel 0 -> encoder latent z [B, r, a, e, z_ch] fp32 (RadarAutoencoder._encode layout)
     int encode(const float* cube, int cube_ch, int B, float** z, hipStream_t st);
+    // the Decoder half of the RadarAutoencoder (models_radar_encoder.py:243-359) on the same kernels: a second object of this class
+    int create_decoder(int ch, int z_ch, int out_ch, int R, int A, int E, DeviceArena* arena);
+    // z [B][R/16][A/16][E/16][z_ch] -> pred4 [B][R][A][E][4] fp32 (the first out_ch channels are the reconstruction)
+    int decode(const float* z, int B, float* pred4, hipStream_t st);
     ~RadarEncoder();
 };
 

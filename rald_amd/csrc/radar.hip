@@ -557,11 +557,35 @@ __global__ void radar_token_kernel(const float* __restrict__ z, const float* __r
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// ---- decoder helpers --------------------------------------------------------------------------------------------------------
+// Upsample (:18-27): nearest-neighbour x2 of the fp32 trunk [B][D][H][W][C] (channels last) -> bf16 [B][2D][2H][2W][C], the input of
+// the 3x3x3 convolution that follows.  One thread per 4 channels of an OUTPUT voxel.
+__global__ __launch_bounds__(256) void upsample2_cast_kernel(const float* __restrict__ x, bf16* __restrict__ y, int B, int D, int H, int W, int C) {
+    const int64_t quads = (int64_t)B * 8 * D * H * W * (C / 4);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < quads; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % (C / 4));
+        int64_t v = i / (C / 4);
+        const int ow = (int)(v % (2 * W)); v /= 2 * W;
+        const int oh = (int)(v % (2 * H)); v /= 2 * H;
+        const int od = (int)(v % (2 * D));
+        const int b = (int)(v / (2 * D));
+        const float4 s = *reinterpret_cast<const float4*>(x + ((((int64_t)b * D + od / 2) * H + oh / 2) * W + ow / 2) * C + 4 * c4);
+        *reinterpret_cast<bf16x4*>(y + i * 4) = pack4(s.x, s.y, s.z, s.w);
+    }
+}
+// z [rows][zc] fp32 -> bf16 [rows][64], zero beyond zc (the decoder's conv_in reads 64-channel rows)
+__global__ __launch_bounds__(256) void pad_cast64_kernel(const float* __restrict__ z, bf16* __restrict__ y, int64_t rows, int zc) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * 64) return;
+    const int c = (int)(i & 63);
+    y[i] = (bf16)(c < zc ? z[(i >> 6) * zc + c] : 0.f);
+}
+
 struct RadarEncoder::Impl {
     int ch = 64, zc = 16, R = 128, A = 64, E = 32, token_ch = 512, cin = 1;
     DeviceArena* arena = nullptr;
     enum Kind { CONV3, CONV1, VEC, CONVIN };
-    struct Tensor { Kind kind; int cout, cin; void* ptr = nullptr; bool loaded = false; };
+    struct Tensor { Kind kind; int cout, cin; void* ptr = nullptr; bool loaded = false; int cin_pad = 0, cout_pad = 0; };   // pads: decoder conv_in / conv_out
     std::map<std::string, Tensor> tensors;
     // tokeniser
     float *w_tok = nullptr, *b_tok = nullptr, *emb_r = nullptr, *emb_a = nullptr, *emb_e = nullptr;
@@ -580,7 +604,14 @@ struct RadarEncoder::Impl {
     int fused_B = 0, fused_S = 0, fused_C = 0;
     int tok_batch = 0;
 
-    void add(const std::string& name, Kind k, int cout, int cin) { tensors[name] = Tensor{k, cout, cin}; }
+    void add(const std::string& name, Kind k, int cout, int cin) { Tensor t{k, cout, cin}; t.cin_pad = cin; t.cout_pad = cout; tensors[name] = t; }
+    // 3x3x3 convolution whose channel counts are padded up for the implicit-GEMM kernel (Cin to 64, Cout to 4): zero weights / bias in the pad
+    void add_conv3_padded(const std::string& n, int cout, int cin, int cout_pad, int cin_pad) {
+        add_conv3(n, cout, cin);
+        tensors[n + ".weight"].cin_pad = cin_pad; tensors[n + ".weight"].cout_pad = cout_pad; tensors[n + ".bias"].cout_pad = cout_pad;
+    }
+    bool is_decoder = false;
+    int out_ch = 2;
     void add_conv3(const std::string& n, int cout, int cin) { add(n + ".weight", CONV3, cout, cin); add(n + ".bias", VEC, cout, 0); }
     void add_conv1(const std::string& n, int cout, int cin) { add(n + ".weight", CONV1, cout, cin); add(n + ".bias", VEC, cout, 0); }
     void add_norm(const std::string& n, int c) { add(n + ".weight", VEC, c, 0); add(n + ".bias", VEC, c, 0); }
@@ -601,9 +632,26 @@ struct RadarEncoder::Impl {
     int resblock(float*& x, float*& t1, float*& t2, const std::string& name, int B, int Dd, int Hh, int Ww, int cin, int cout, hipStream_t st);
     int attnblock(float* x, const std::string& name, int B, int S, int C, hipStream_t st);
     int forward(const float* cube, int cube_ch, int B, float* zout, hipStream_t st);
+    int decode(const float* z, int B, float* out, hipStream_t st);     // Decoder.forward (:333-359), nsub samples
 };
 
 static const int kChMult[5] = {1, 1, 2, 2, 4};
+
+static int radar_alloc_tensors(RadarEncoder::Impl& m, DeviceArena* arena) {
+    for (auto& kv : m.tensors) {
+        auto& t = kv.second;
+        size_t bytes = 0;
+        switch (t.kind) {
+            case RadarEncoder::Impl::CONV3: bytes = (size_t)t.cout_pad * 27 * t.cin_pad * 2; break;
+            case RadarEncoder::Impl::CONV1: bytes = (size_t)t.cout * t.cin * 2; break;
+            case RadarEncoder::Impl::VEC: bytes = (size_t)t.cout_pad * 4; break;
+            case RadarEncoder::Impl::CONVIN: bytes = (size_t)t.cout * t.cin * 27 * 4; break;
+        }
+        t.ptr = arena->alloc(bytes < 64 ? 64 : bytes, true);       // >= 16 floats so float4 bias reads of a 16-ch tail stay in bounds; pads stay zero
+        RALD_CHECK(t.ptr, "radar encoder: weight allocation failed");
+    }
+    return 0;
+}
 
 int RadarEncoder::create(int ch, int z_ch, int R, int A, int E, int token_ch, DeviceArena* arena, int in_channels) {
     RALD_CHECK(in_channels == 1 || in_channels == 2, "radar encoder: in_channels must be 1 or 2");
@@ -632,18 +680,7 @@ int RadarEncoder::create(int ch, int z_ch, int R, int A, int E, int token_ch, De
     m.add_res("mid.block_2", block_in, block_in);
     m.add_norm("norm_out", block_in);
     m.add_conv3("conv_out", z_ch, block_in);
-    for (auto& kv : m.tensors) {
-        auto& t = kv.second;
-        size_t bytes = 0;
-        switch (t.kind) {
-            case Impl::CONV3: bytes = (size_t)t.cout * 27 * t.cin * 2; break;
-            case Impl::CONV1: bytes = (size_t)t.cout * t.cin * 2; break;
-            case Impl::VEC: bytes = (size_t)t.cout * 4; break;
-            case Impl::CONVIN: bytes = (size_t)t.cout * t.cin * 27 * 4; break;
-        }
-        t.ptr = arena->alloc(bytes < 64 ? 64 : bytes, true);       // >= 16 floats so float4 bias reads of a 16-ch tail stay in bounds
-        RALD_CHECK(t.ptr, "radar encoder: weight allocation failed");
-    }
+    RALD_TRY(radar_alloc_tensors(m, arena));
     const int nt_r = R / 16, nt_a = A / 16, nt_e = E / 16;
     m.w_tok = (float*)arena->alloc((size_t)token_ch * z_ch * 4, true);
     m.b_tok = (float*)arena->alloc((size_t)token_ch * 4, true);
@@ -651,6 +688,35 @@ int RadarEncoder::create(int ch, int z_ch, int R, int A, int E, int token_ch, De
     m.emb_a = (float*)arena->alloc((size_t)nt_a * token_ch * 4, true);
     m.emb_e = (float*)arena->alloc((size_t)nt_e * token_ch * 4, true);
     RALD_CHECK(m.w_tok && m.b_tok && m.emb_r && m.emb_a && m.emb_e, "radar encoder: allocation failed");
+    return 0;
+}
+
+// Decoder of the RadarAutoencoder (models_radar_encoder.py:243-359): conv_in z_ch -> 4ch, mid (ResnetBlock, AttnBlock, ResnetBlock), five
+// levels from the coarsest up - three ResnetBlocks each, nearest-neighbour x2 + conv3x3 between levels -, GroupNorm + swish + conv_out.
+// Same kernels as the encoder; conv_in's z_ch inputs are zero-padded to 64 channels and conv_out's out_ch outputs to 4.
+int RadarEncoder::create_decoder(int ch, int z_ch, int out_ch, int R, int A, int E, DeviceArena* arena) {
+    RALD_CHECK(ch % 64 == 0 && ch >= 64, "radar decoder: hidden channels must be a multiple of 64");
+    RALD_CHECK(R % 16 == 0 && A % 16 == 0 && E % 16 == 0, "radar decoder: cube dims must be multiples of 16");
+    RALD_CHECK(z_ch >= 1 && z_ch <= 64 && out_ch >= 1 && out_ch <= 4, "radar decoder: z channels <= 64, output channels <= 4");
+    impl = new Impl();
+    Impl& m = *impl;
+    m.ch = ch; m.zc = z_ch; m.R = R; m.A = A; m.E = E; m.arena = arena; m.is_decoder = true; m.out_ch = out_ch;
+    int block_in = ch * kChMult[4];
+    m.add_conv3_padded("conv_in", block_in, z_ch, block_in, 64);
+    m.add_res("mid.block_1", block_in, block_in);
+    m.add_attn("mid.attn_1", block_in);
+    m.add_res("mid.block_2", block_in, block_in);
+    for (int l = 4; l >= 0; --l) {
+        const int block_out = ch * kChMult[l];
+        for (int b = 0; b < 3; ++b) {
+            m.add_res("up." + std::to_string(l) + ".block." + std::to_string(b), block_in, block_out);
+            block_in = block_out;
+        }
+        if (l != 0) m.add_conv3("up." + std::to_string(l) + ".upsample.conv", block_in, block_in);
+    }
+    m.add_norm("norm_out", block_in);
+    m.add_conv3_padded("conv_out", out_ch, block_in, 4, block_in);
+    RALD_TRY(radar_alloc_tensors(m, arena));
     return 0;
 }
 
@@ -674,7 +740,7 @@ int RadarEncoder::load_weight(const std::string& name, const float* data, int64_
     switch (t.kind) {
         case Impl::VEC:
             RALD_CHECK(nelem == t.cout, "radar encoder: size mismatch for '" + name + "'");
-            RALD_TRY(st.to_f32(data, (float*)t.ptr, 1, t.cout, t.cout, nullptr));
+            RALD_TRY(st.to_f32(data, (float*)t.ptr, 1, t.cout, t.cout, nullptr));      // (a padded tail stays zero)
             break;
         case Impl::CONVIN:
             RALD_CHECK(nelem == (int64_t)t.cout * t.cin * 27, "radar encoder: size mismatch for '" + name + "'");
@@ -693,7 +759,7 @@ int RadarEncoder::load_weight(const std::string& name, const float* data, int64_
                 for (int ci = 0; ci < t.cin; ++ci)
                     for (int tp = 0; tp < 27; ++tp)
                         dst[((size_t)co * 27 + tp) * t.cin + ci] = src[((size_t)co * t.cin + ci) * 27 + tp];
-            RALD_TRY(st.to_bf16(dst.data(), (bf16*)t.ptr, t.cout * 27, t.cin, t.cin, nullptr));
+            RALD_TRY(st.to_bf16(dst.data(), (bf16*)t.ptr, t.cout * 27, t.cin, t.cin_pad, nullptr));   // rows of cin_pad, zero beyond cin
             break;
         }
     }
@@ -884,6 +950,56 @@ int RadarEncoder::Impl::forward(const float* cube, int cube_ch, int B, float* zo
     RALD_TRY(resblock(x, t1, t2, "mid.block_2", B, Dd, Hh, Ww, cin, cin, st));
     RALD_TRY(gn(x, "norm_out", n16, B, Dd * Hh * Ww, cin, true, st));
     RALD_TRY(run_conv(n16, "conv_out", nullptr, zout, B, Dd, Hh, Ww, cin, zc, 1, 1, st));
+    return 0;
+}
+
+int RadarEncoder::Impl::decode(const float* zin, int B, float* out, hipStream_t st) {
+    for (const auto& kv : tensors) RALD_CHECK(kv.second.loaded, "radar decoder: missing key '" + kv.first + "'");
+    RALD_TRY(ensure_ws(B));
+    float *x = f0, *t1 = f1, *t2 = f2;
+    fused_src = nullptr;
+    int Dd = R / 16, Hh = A / 16, Ww = E / 16;
+    int cin = ch * kChMult[4];
+    {
+        const int64_t rows = (int64_t)B * Dd * Hh * Ww;
+        hipLaunchKernelGGL(pad_cast64_kernel, dim3((unsigned)((rows * 64 + 255) / 256)), dim3(256), 0, st, zin, n16, rows, zc);
+        RALD_HIP(hipGetLastError());
+        RALD_TRY(run_conv(n16, "conv_in", nullptr, x, B, Dd, Hh, Ww, 64, cin, 1, 1, st));
+    }
+    RALD_TRY(resblock(x, t1, t2, "mid.block_1", B, Dd, Hh, Ww, cin, cin, st));
+    RALD_TRY(attnblock(x, "mid.attn_1", B, Dd * Hh * Ww, cin, st));
+    RALD_TRY(resblock(x, t1, t2, "mid.block_2", B, Dd, Hh, Ww, cin, cin, st));
+    for (int l = 4; l >= 0; --l) {
+        const int cout = ch * kChMult[l];
+        for (int b = 0; b < 3; ++b) {
+            RALD_TRY(resblock(x, t1, t2, "up." + std::to_string(l) + ".block." + std::to_string(b), B, Dd, Hh, Ww, cin, cout, st));
+            cin = cout;
+        }
+        if (l != 0) {
+            const int64_t quads = (int64_t)B * 8 * Dd * Hh * Ww * (cin / 4);
+            const unsigned blocks = (unsigned)((quads + 255) / 256 < 8192 ? (quads + 255) / 256 : 8192);
+            hipLaunchKernelGGL(upsample2_cast_kernel, dim3(blocks), dim3(256), 0, st, x, n16, B, Dd, Hh, Ww, cin);
+            RALD_HIP(hipGetLastError());
+            Dd *= 2; Hh *= 2; Ww *= 2;
+            RALD_TRY(run_conv(n16, "up." + std::to_string(l) + ".upsample.conv", nullptr, t1, B, Dd, Hh, Ww, cin, cin, 1, 1, st));
+            std::swap(x, t1);
+        }
+    }
+    RALD_TRY(gn(x, "norm_out", n16, B, Dd * Hh * Ww, cin, true, st));
+    RALD_TRY(run_conv(n16, "conv_out", nullptr, out, B, Dd, Hh, Ww, cin, 4, 1, 1, st));       // [B][R][A][E][4]: channels 0..out_ch-1 are the reconstruction
+    return 0;
+}
+
+// z [B][R/16][A/16][E/16][z_ch] fp32 (the layout RadarAutoencoder._encode returns) -> pred4 [B][R][A][E][4] fp32 (out_ch real channels + zero pad)
+int RadarEncoder::decode(const float* z, int B, float* pred4, hipStream_t st) {
+    RALD_CHECK(impl && impl->is_decoder && z && pred4 && B >= 1, "radar decoder: bad arguments");
+    Impl& m = *impl;
+    const int SUB = 4;
+    const size_t zs = (size_t)(m.R / 16) * (m.A / 16) * (m.E / 16) * m.zc, os = (size_t)m.R * m.A * m.E * 4;
+    for (int b0 = 0; b0 < B; b0 += SUB) {
+        const int nb = B - b0 < SUB ? B - b0 : SUB;
+        RALD_TRY(m.decode(z + (size_t)b0 * zs, nb, pred4 + (size_t)b0 * os, st));
+    }
     return 0;
 }
 

@@ -251,6 +251,8 @@ def main():
         golden_stress_ae()
     if want("g19"):
         golden_stress_dit()
+    if want("g20"):
+        golden_radar_autoencoder_forward()
     print(f"done in {time.time() - t00:.0f}s")
 
 
@@ -268,6 +270,24 @@ def golden_radar_autoencoder():
         z = m._encode(synth.radar_cube(2))
     save("g8_radar_autoencoder.npz", z=z)
 
+
+
+def golden_radar_autoencoder_forward():
+    """G20: RadarAutoencoder.forward (models_radar_encoder.py:395-406) and .decode (:386-388) of
+    ae_ch64_mult5_n2_d16 on one seeded cube.  The reconstruction [1,128,64,32,2] is 2 MB: every 4th voxel per axis is stored plus
+    whole-tensor checksums; the latent is stored whole (it is also the decoder-only input)."""
+    G, A, R = import_reference()
+    import contextlib, io
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        m = R.ae_ch64_mult5_n2_d16()
+    seed_module(m, 0)
+    with torch.no_grad():
+        out = m(synth.radar_cube(1))
+        pred, z = out["pred"], out["latent"]
+        dec = m.decode(z).permute(0, 2, 3, 4, 1)
+        assert torch.equal(dec, pred)
+    save("g20_radar_autoencoder_forward.npz", latent=z, pred_s4=pred[:, ::4, ::4, ::4], pred_sum=np.float64(pred.double().sum()),
+         pred_abs_sum=np.float64(pred.double().abs().sum()), pred_sq_sum=np.float64(pred.double().pow(2).sum()))
 
 
 def golden_postprocess():

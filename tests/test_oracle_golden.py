@@ -234,3 +234,15 @@ def test_g13_g17_long_sampler_horizons():
         cond = O.process_radar_cond(sd, synth.radar_cube(1))
         s = O.edm_sampler(lambda xx, ss: O.edm_precond(sd, xx, ss, cond, depth=depth), synth.latents([0]), num_steps=steps)
         assert rel_l2(s, load_golden(fname)["sample"]) < 1e-4
+
+
+def test_g20_radar_autoencoder_forward_and_decode():
+    """RadarAutoencoder.forward / decode (reconstruction) against the reference."""
+    g = load_golden("g20_radar_autoencoder_forward.npz")
+    sd = weights.make_state_dict(weights.radar_autoencoder_spec(64), 0)
+    out = O.radar_autoencoder_forward(sd, synth.radar_cube(1))
+    assert rel_l2(out["latent"], g["latent"]) < TOL
+    pred = out["pred"]
+    assert rel_l2(pred[:, ::4, ::4, ::4], g["pred_s4"]) < TOL
+    assert abs(float(pred.double().abs().sum()) - float(g["pred_abs_sum"])) < 1e-4 * float(g["pred_abs_sum"])
+    assert abs(float(pred.double().pow(2).sum()) - float(g["pred_sq_sum"])) < 1e-4 * float(g["pred_sq_sum"])
