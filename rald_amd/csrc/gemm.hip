@@ -463,6 +463,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_glds_kernel(GemmArgs a) 
 // (tools/ab_persist.py): FF1 alone 155.1 vs 151.6 us, whole NFE at B = 64 12.75 vs 12.60 ms, with the stagger 12.86 ms - the
 // hardware dispatcher already starts the next workgroup of a CU while the previous one drains its stores, and the tile loop
 // costs the double-buffered fragment registers of the plain kernel's main loop.  Kept as a measured dead end.
+// Round 3 rebuilt it on the rotated main loop WITH the double-buffered fragments (scalar base + 32-bit lane offsets for the DMA sources,
+// one code path for the last tile, bias through LDS-DMA; clean k-loop, 52 spilled registers at the tile boundaries): correct, and 7 % SLOWER
+// per NFE (FF1 143 -> ~176 us at B = 64).  The reason is structural: vmcnt is per wave and in order, so the next tile's second hand-over
+// (its stage 2 was issued behind the epilogue's stores) waits for this wave's own stores - and those are part of a chip-wide burst
+// (16.8 MB per round of tiles, all CUs at once) that takes ~4 us to drain.  In the plain launch the next workgroup's waves start with
+// empty counters and never wait for the previous workgroup's stores.  A persistent GEMM with an HBM-write-through epilogue pays its own
+// store latency; the plain launch does not.
 // =================================================================================================
 // One workgroup per CU walks its tiles (virtual block id v = blockIdx.x + j * gridDim.x through the same XCD-aware strip order
 // as above: v % 8 == blockIdx.x % 8, so a workgroup's tiles stay on its XCD's L2).  What the plain launch cannot do:
