@@ -300,6 +300,9 @@ int rald_op_transpose(const void* in, int32_t in_is_bf16, int64_t ld_in, int64_t
  * dx += ..., dscale[g] += sum_rows dh * xhat, dshift[g] += sum_rows dh  (g = row / rows_per_group, stride gstride) */
 int rald_op_ln_mod_bwd(const float* x, const float* dh, const float* scale, int64_t gstride, int32_t rows_per_group, float add_one, float eps,
                        int64_t rows, int32_t D, float* dx_accum, float* dscale_accum, float* dshift_accum, void* stream);
+/* the same, and the updated dx also as bf16 [rows][512] (what the next weight-/input-gradient GEMMs of the block read) */
+int rald_op_ln_mod_bwd_cast(const float* x, const float* dh, const float* scale, int64_t gstride, int32_t rows_per_group, float add_one, float eps,
+                            int64_t rows, int32_t D, float* dx_accum, void* dx_bf16_out, float* dscale_accum, float* dshift_accum, void* stream);
 /* GEGLU :88-95 in the natural layout u = [a | g] (2*inner columns): hid = a * gelu_erf(g); and its backward */
 int rald_op_geglu_fwd(const void* u_bf16, void* hid_bf16, int64_t M, int32_t inner, void* stream);
 int rald_op_geglu_bwd(const void* u_bf16, const void* dhid_bf16, void* du_bf16, int64_t M, int32_t inner, void* stream);
@@ -431,6 +434,14 @@ int rald_op_attention_split(const void* Q, int64_t ldq, int64_t strideQ, const v
 int rald_op_attention_vrow(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK, const void* V, int64_t ldv,
                            int64_t strideV, void* O, int64_t ldo, int64_t strideO, int32_t nq, int32_t nk, int32_t heads, int32_t batch, float scale,
                            void* stream);
+/* gradients of rald_op_attention_vrow's O = softmax(Q K^T scale) V per head (torch autograd of CrossAttention,
+ * model/models_radar_generation.py:66-75, in the training step engine_generation.py:74-98): dQ, dK, dV bf16 in the layouts of Q, K, V
+ * (own leading dimensions and batch strides: column slices of fused buffers are fine).  Two launches, nothing score-shaped in memory.
+ * lse_scratch / delta_scratch: fp32 [batch*heads*nq] each.  nq % 128 == 0, nk % 64 == 0. */
+int rald_op_attention_bwd(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK, const void* V, int64_t ldv,
+                          int64_t strideV, const void* O, int64_t ldo, int64_t strideO, const void* dO, int64_t lddo, int64_t strideDO,
+                          void* dQ, int64_t lddq, int64_t strideDQ, void* dK, int64_t lddk, int64_t strideDK, void* dV, int64_t lddv, int64_t strideDV,
+                          float* lse_scratch, float* delta_scratch, int32_t nq, int32_t nk, int32_t heads, int32_t batch, float scale, void* stream);
 /* fused residual GEMM + next LayerNorm (N = 512): x[M][512] += A[M][K].W[512][K]^T + bias (fp32, in place);
  * h_bf16 = LayerNorm(x) * (add_one + g[row/rows_per_group*gstride + c]) + b[...] */
 int rald_op_gemm_resid_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* x, void* h_bf16,

@@ -98,6 +98,8 @@ SIGNATURES = {
     "rald_op_transpose": (c_int, [c_void_p, c_int, c_i64, c_i64, c_i64, c_void_p, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_void_p]),
     "rald_op_ln_mod_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_float, c_float, c_i64, c_int, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),
+    "rald_op_ln_mod_bwd_cast": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_float, c_float, c_i64, c_int, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p]),
     "rald_op_geglu_fwd": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p]),
     "rald_op_geglu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
     "rald_op_colsum": (c_int, [c_void_p, c_int, c_i64, c_i64, c_int, c_void_p, c_void_p]),
@@ -151,6 +153,7 @@ SIGNATURES = {
                                         c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p]),
     "rald_op_attention_vrow": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64,
                                        c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "rald_op_attention_bwd": (c_int, [c_void_p, c_i64, c_i64] * 8 + [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "rald_op_gemm_resid_ln": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int,
                                       c_float, c_float, c_int, c_int, c_void_p]),
     "rald_op_cast_bf16": (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),

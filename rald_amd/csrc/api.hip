@@ -332,6 +332,11 @@ int rald_op_ln_mod_bwd(const float* x, const float* dh, const float* scale, int6
     RALD_CHECK(x && dh && scale && dx_accum && dscale_accum && dshift_accum, "rald_op_ln_mod_bwd: null pointer");
     return ln_mod_bwd(x, dh, scale, gstride, rows_per_group, add_one, eps, rows, D, dx_accum, dscale_accum, dshift_accum, (hipStream_t)stream);
 }
+int rald_op_ln_mod_bwd_cast(const float* x, const float* dh, const float* scale, int64_t gstride, int32_t rows_per_group, float add_one, float eps,
+                            int64_t rows, int32_t D, float* dx_accum, void* dx_bf16_out, float* dscale_accum, float* dshift_accum, void* stream) {
+    RALD_CHECK(x && dh && scale && dx_accum && dx_bf16_out && dscale_accum && dshift_accum, "rald_op_ln_mod_bwd_cast: null pointer");
+    return ln_mod_bwd(x, dh, scale, gstride, rows_per_group, add_one, eps, rows, D, dx_accum, dscale_accum, dshift_accum, (hipStream_t)stream, (bf16*)dx_bf16_out);
+}
 int rald_op_geglu_fwd(const void* u_bf16, void* hid_bf16, int64_t M, int32_t inner, void* stream) {
     RALD_CHECK(u_bf16 && hid_bf16, "rald_op_geglu_fwd: null pointer");
     return geglu_fwd((const bf16*)u_bf16, (bf16*)hid_bf16, M, inner, (hipStream_t)stream);
@@ -476,6 +481,17 @@ int rald_op_attention_vrow(const void* Q, int64_t ldq, int64_t strideQ, const vo
     a.O = (bf16*)O; a.ldo = ldo; a.strideO = strideO;
     a.nq = nq; a.nk = nk; a.k_rows = nk; a.heads = heads; a.batch = batch; a.scale = scale; a.q_prescaled = 0;
     return attention_d64(a, (hipStream_t)stream);
+}
+int rald_op_attention_bwd(const void* Q, int64_t ldq, int64_t strideQ, const void* K, int64_t ldk, int64_t strideK, const void* V, int64_t ldv,
+                          int64_t strideV, const void* O, int64_t ldo, int64_t strideO, const void* dO, int64_t lddo, int64_t strideDO,
+                          void* dQ, int64_t lddq, int64_t strideDQ, void* dK, int64_t lddk, int64_t strideDK, void* dV, int64_t lddv, int64_t strideDV,
+                          float* lse_scratch, float* delta_scratch, int32_t nq, int32_t nk, int32_t heads, int32_t batch, float scale, void* stream) {
+    AttnBwdArgs a;
+    a.Q = (const bf16*)Q; a.ldq = ldq; a.sq = strideQ; a.K = (const bf16*)K; a.ldk = ldk; a.sk = strideK; a.V = (const bf16*)V; a.ldv = ldv; a.sv = strideV;
+    a.O = (const bf16*)O; a.ldo = ldo; a.so = strideO; a.dO = (const bf16*)dO; a.lddo = lddo; a.sdo = strideDO;
+    a.dQ = (bf16*)dQ; a.lddq = lddq; a.sdq = strideDQ; a.dK = (bf16*)dK; a.lddk = lddk; a.sdk = strideDK; a.dV = (bf16*)dV; a.lddv = lddv; a.sdv = strideDV;
+    a.lse = lse_scratch; a.delta = delta_scratch; a.nq = nq; a.nk = nk; a.heads = heads; a.batch = batch; a.scale = scale;
+    return attention_bwd_d64(a, (hipStream_t)stream);
 }
 // fp16 shared-key form (the folded encoder attentions, ae_encode.hip): fp32 pre-scaled queries [batch?][nq][heads*64], ONE fp16 row per key
 // [batch][k_rows][64] that is key and value of every head; rows nk .. k_rows-1 must be zero

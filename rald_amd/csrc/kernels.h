@@ -125,6 +125,20 @@ int attention_d64(const AttnArgs& a, hipStream_t st);
 int attention_pick_ksplit(int nq, int nk, int heads, int batch);
 inline int64_t attention_split_scratch_bytes(int ksplit, int nq, int heads, int batch) { return (int64_t)ksplit * batch * heads * nq * 66 * 4; }
 
+// ---------------------------------------------------------------- attn_bwd.hip (training: gradients of the attention above)
+// dQ, dK, dV of O = softmax(Q K^T scale) V per head; every operand bf16 [b][row][h*64 + d] with its row and batch strides (column
+// slices of fused buffers are fine).  lse / delta: fp32 scratch of batch*heads*nq elements each (written, then read).
+struct AttnBwdArgs {
+    const bf16 *Q, *K, *V, *O, *dO;
+    int64_t ldq, sq, ldk, sk, ldv, sv, ldo, so, lddo, sdo;
+    bf16 *dQ, *dK, *dV;
+    int64_t lddq, sdq, lddk, sdk, lddv, sdv;
+    float *lse, *delta;
+    int nq, nk, heads, batch;
+    float scale;
+};
+int attention_bwd_d64(const AttnBwdArgs& a, hipStream_t st);
+
 // ---------------------------------------------------------------- attn_small.hip (<= 2048 rows: fused per-head sub-blocks)
 // part[h][row][512] = (softmax(q_h k_h^T) v_h) . Wo[:, 64h:64h+64]^T  for the fused q|k|v buffer of a self-attention
 int attn_self_proj(const bf16* qkv, int64_t ld, const bf16* Wo, float* part, int NL, int heads, int batch, hipStream_t st, bool part_f16 = false);
@@ -262,7 +276,7 @@ struct TransposeArgs {
 };
 int transpose_rows(const TransposeArgs& a, int in_is_bf16, hipStream_t st);
 int ln_mod_bwd(const float* x, const float* dh, const float* s, int64_t gstride, int rows_per_group, float add_one, float eps, int64_t rows,
-               int D, float* dx, float* ds, float* dt, hipStream_t st);
+               int D, float* dx, float* ds, float* dt, hipStream_t st, bf16* dx_bf16 = nullptr);
 int geglu_fwd(const bf16* u, bf16* hid, int64_t M, int I, hipStream_t st);
 int geglu_bwd(const bf16* u, const bf16* dhid, bf16* du, int64_t M, int I, hipStream_t st);
 int colsum(const void* X, int is_bf16, int64_t ld, int64_t M, int N, float* out, hipStream_t st);

@@ -87,7 +87,7 @@ int transpose_rows(const TransposeArgs& a, int in_is_bf16, hipStream_t st) {
 // rows_per_group % 16 == 0), column sums reduced through LDS, one atomicAdd per column per workgroup.
 __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dh, const float* __restrict__ s,
                                                          int64_t gstride, int rows_per_group, float add_one, float eps, int64_t rows,
-                                                         float* __restrict__ dx, float* __restrict__ ds, float* __restrict__ dt) {
+                                                         float* __restrict__ dx, bf16* __restrict__ dxb, float* __restrict__ ds, float* __restrict__ dt) {
     constexpr int D = 512, RPW = 4;                          // 4 waves x 4 rows
     __shared__ float red[2][4][D];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -132,6 +132,12 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict
         o1.z += rstd * (gh[6] - m1 - v[6] * m2); o1.w += rstd * (gh[7] - m1 - v[7] * m2);
         *reinterpret_cast<float4*>(o) = o0;
         *reinterpret_cast<float4*>(o + 4) = o1;
+        if (dxb) {                                            // the bf16 copy the next weight-gradient / input-gradient GEMMs read
+            bf16x8 ob;
+            ob[0] = (bf16)o0.x; ob[1] = (bf16)o0.y; ob[2] = (bf16)o0.z; ob[3] = (bf16)o0.w;
+            ob[4] = (bf16)o1.x; ob[5] = (bf16)o1.y; ob[6] = (bf16)o1.z; ob[7] = (bf16)o1.w;
+            *reinterpret_cast<bf16x8*>(dxb + row * D + lane * 8) = ob;
+        }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) { red[0][wave][lane * 8 + i] = as[i]; red[1][wave][lane * 8 + i] = at[i]; }
@@ -144,11 +150,12 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict
 }
 
 int ln_mod_bwd(const float* x, const float* dh, const float* s, int64_t gstride, int rows_per_group, float add_one, float eps, int64_t rows,
-               int D, float* dx, float* ds, float* dt, hipStream_t st) {
+               int D, float* dx, float* ds, float* dt, hipStream_t st, bf16* dx_bf16) {
     RALD_CHECK(D == 512, "ln_mod_bwd: D must be 512");
+    RALD_CHECK((uintptr_t)dx_bf16 % 16 == 0, "ln_mod_bwd: the bf16 copy must be 16-byte aligned");
     RALD_CHECK(rows > 0 && rows_per_group > 0 && (rows_per_group % 16 == 0 || rows_per_group >= rows), "ln_mod_bwd: rows_per_group must be a multiple of 16");
     hipLaunchKernelGGL(ln_mod_bwd_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, x, dh, s, gstride, rows_per_group, add_one, eps, rows,
-                       dx, ds, dt);
+                       dx, dx_bf16, ds, dt);
     RALD_HIP(hipGetLastError());
     return 0;
 }

@@ -243,12 +243,13 @@ class DitTrainer:
         dyn = torch.zeros(M, D, **f32)
         sgemm_acc(dF, P["proj_out.weight"].data, dyn, trans_b=True)                              # dyn = dF . W_out
         dx = torch.zeros(M, D, **f32)
-        TO.ln_mod_bwd(x_final, dyn, ng, 0, 1 << 30, 0.0, dx, self._grad("norm.weight"), self._grad("norm.bias"))
+        dxb = torch.empty(M, D, device=dev, dtype=torch.bfloat16)               # bf16(dx), kept current by every LayerNorm backward
+        TO.ln_mod_bwd(x_final, dyn, ng, 0, 1 << 30, 0.0, dx, self._grad("norm.weight"), self._grad("norm.bias"), dx_bf16=dxb)
         dmod = torch.zeros(Bn, L * 3, 2 * D, **f32)
         dcond = torch.zeros(Bn * T, cond16.shape[1], **f32)
         for i in reversed(range(L)):
             grads, pending = self._block_grad_views(i)
-            _, _, dc = TO.block_backward(self.W[i], saved[i], dx, dmod[:, 3 * i:3 * i + 3], grads)
+            _, _, dc = TO.block_backward(self.W[i], saved[i], dx, dmod[:, 3 * i:3 * i + 3], grads, dxb=dxb)
             saved[i] = None
             dcond += dc
             for name, key, rows in pending:                 # q/k/v gradients not adjacent in memory: split the fused one

@@ -6,10 +6,10 @@ every product is a bf16 MFMA GEMM through ``rald_op_gemm_nt[2]`` (fp32 accumulat
 transposed weight, dW = dY^T.X with transposed activations), everything else a streaming kernel of
 ``csrc/train_kernels.hip``.  PyTorch only owns the buffers.
 
-Attention backward is the unfused form: S = Q.K^T and dP = dO.V^T per head as batched K = 64 GEMMs, the
-softmax backward element-wise; the key-side gradients use the transposed orientation (S^T = K.Q^T,
-dP^T = V.dO^T, with the query's log-sum-exp and delta broadcast along columns), which costs two more thin
-GEMMs instead of transposing the [heads, N, N] probability tensors.
+Attention backward is two fused launches (csrc/attn_bwd.hip: a query-side and a key-side kernel that recompute the
+probabilities from the log-sum-exp, flash-attention style); shapes they do not cover take the unfused form: S = Q.K^T
+and dP = dO.V^T per head as batched K = 64 GEMMs, the softmax backward element-wise, the key-side gradients in the
+transposed orientation.
 
 Gradient parity against autograd of the CPU oracle: tests/test_train_block.py (one block, whole denoiser);
 the loop over blocks, embeddings and loss live in train_dit.py, the radar encoder in train_encoder.py.
@@ -21,7 +21,7 @@ from typing import Dict, Tuple
 
 import torch
 
-from ._handles import _ptr, _stream, op_attention, op_gemm_nt, op_gemm_tn, op_layernorm
+from ._handles import _ptr, _stream, op_attention, op_attention_vrow, op_gemm_nt, op_gemm_tn, op_layernorm
 from ._lib import check, lib
 
 HEAD = 64
@@ -57,7 +57,12 @@ def T2(x: torch.Tensor) -> torch.Tensor:
     return transpose(x, x.shape[0], x.shape[1], x.stride(0)).reshape(x.shape[1], x.shape[0])
 
 
-def ln_mod_bwd(x, dh, scale, gstride, rows_per_group, add_one, dx, dscale, dshift, eps=1e-5):
+def ln_mod_bwd(x, dh, scale, gstride, rows_per_group, add_one, dx, dscale, dshift, eps=1e-5, dx_bf16=None):
+    """dx += LayerNorm-mod backward of dh (fp32, in place); dx_bf16 (optional, bf16 [rows, 512]) receives the updated dx rounded to bf16."""
+    if dx_bf16 is not None:
+        check(lib().rald_op_ln_mod_bwd_cast(_p(x), _p(dh), _p(scale), gstride, rows_per_group, add_one, eps, x.shape[0], x.shape[1], _p(dx),
+                                            _p(dx_bf16), _p(dscale), _p(dshift), C.c_void_p(_stream())))
+        return
     check(lib().rald_op_ln_mod_bwd(_p(x), _p(dh), _p(scale), gstride, rows_per_group, add_one, eps, x.shape[0], x.shape[1], _p(dx), _p(dscale),
                                    _p(dshift), C.c_void_p(_stream())))
 
@@ -91,7 +96,20 @@ def colsum(x: torch.Tensor, out: torch.Tensor) -> None:
 
 def attention_backward(q, ldq, k, ldk, v, ldv, O, dO, Bn: int, H: int, nq: int, nk: int, dq, ld_dq, dk, ld_dk, dv, ld_dv):
     """Gradients of O = softmax(q k^T / 8) v per head (models_radar_generation.py:56-74).  q/k/v/dq/dk/dv are bf16
-    tensors (possibly column slices of a fused buffer: pass the slice and its row stride); O, dO [Bn*nq, H*64] bf16."""
+    tensors (possibly column slices of a fused buffer: pass the slice and its row stride); O, dO [Bn*nq, H*64] bf16.
+    Two launches of csrc/attn_bwd.hip (nothing score-shaped in memory) when nq % 128 == 0 and nk % 64 == 0 - the denoiser's
+    512 latents x 512 / 64 keys; other shapes take the unfused GEMM form below."""
+    if nq % 128 or nk % 64:
+        return attention_backward_unfused(q, ldq, k, ldk, v, ldv, O, dO, Bn, H, nq, nk, dq, ld_dq, dk, ld_dk, dv, ld_dv)
+    scratch = torch.empty(2, Bn * H * nq, device=O.device, dtype=torch.float32)
+    check(lib().rald_op_attention_bwd(_p(q), ldq, nq * ldq, _p(k), ldk, nk * ldk, _p(v), ldv, nk * ldv, _p(O), O.stride(0), nq * O.stride(0),
+                                      _p(dO), dO.stride(0), nq * dO.stride(0), _p(dq), ld_dq, nq * ld_dq, _p(dk), ld_dk, nk * ld_dk,
+                                      _p(dv), ld_dv, nk * ld_dv, _p(scratch[0]), _p(scratch[1]), nq, nk, H, Bn, HEAD ** -0.5, C.c_void_p(_stream())))
+
+
+def attention_backward_unfused(q, ldq, k, ldk, v, ldv, O, dO, Bn: int, H: int, nq: int, nk: int, dq, ld_dq, dk, ld_dk, dv, ld_dv):
+    """The same gradients as batched GEMMs + element-wise passes (any nq, nk): S = Q.K^T and dP = dO.V^T per head as K = 64 GEMMs
+    with fp32 results, the softmax backward element-wise, the key side in the transposed orientation."""
     dev, scale = O.device, HEAD ** -0.5
     f32 = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
     b16 = lambda *s: torch.empty(*s, device=dev, dtype=torch.bfloat16)
@@ -143,16 +161,23 @@ def block_forward(W, x: torch.Tensor, mod: torch.Tensor, cond: torch.Tensor, Bn:
     sv["x0"] = x.clone()
     sv["h1"] = ln(0)
     qkv = op_gemm_nt(sv["h1"], W["qkv"])                                          # [M, 1536]
-    vt = transpose(qkv[:, 2 * D:], NL, D, 3 * D, Bn, NL * 3 * D).reshape(Bn, D, NL)
     q3 = qkv.view(Bn, NL, 3 * D)
-    sv["qkv"], sv["o1"] = qkv, op_attention(q3[:, :, :D], q3[:, :, D:2 * D], vt, NL, H, HEAD ** -0.5).reshape(M, D)
+    if NL % 64 == 0:                                                                # V read row-major from the fused buffer (no transposed copy)
+        o1 = op_attention_vrow(q3[:, :, :D], q3[:, :, D:2 * D], q3[:, :, 2 * D:], H, HEAD ** -0.5)
+    else:
+        vt = transpose(qkv[:, 2 * D:], NL, D, 3 * D, Bn, NL * 3 * D).reshape(Bn, D, NL)
+        o1 = op_attention(q3[:, :, :D], q3[:, :, D:2 * D], vt, NL, H, HEAD ** -0.5)
+    sv["qkv"], sv["o1"] = qkv, o1.reshape(M, D)
     op_gemm_nt(sv["o1"], W["o"], bias=W["bo"], epilogue=2, C_inout=x)
     sv["x1"] = x.clone()
     sv["h2"] = ln(1)
     sv["q2"] = op_gemm_nt(sv["h2"], W["q2"])
     sv["kc"], sv["vc"] = op_gemm_nt(cond, W["k2"]), op_gemm_nt(cond, W["v2"])     # [Bn*T, 512]
-    vct = transpose(sv["vc"], T, D, D, Bn, T * D).reshape(Bn, D, T)
-    sv["o2"] = op_attention(sv["q2"].view(Bn, NL, D), sv["kc"].view(Bn, T, D), vct, T, H, HEAD ** -0.5).reshape(M, D)
+    if T % 64 == 0:
+        sv["o2"] = op_attention_vrow(sv["q2"].view(Bn, NL, D), sv["kc"].view(Bn, T, D), sv["vc"].view(Bn, T, D), H, HEAD ** -0.5).reshape(M, D)
+    else:
+        vct = transpose(sv["vc"], T, D, D, Bn, T * D).reshape(Bn, D, T)
+        sv["o2"] = op_attention(sv["q2"].view(Bn, NL, D), sv["kc"].view(Bn, T, D), vct, T, H, HEAD ** -0.5).reshape(M, D)
     op_gemm_nt(sv["o2"], W["o2"], bias=W["bo2"], epilogue=2, C_inout=x)
     sv["x2"] = x.clone()
     sv["h3"] = ln(2)
@@ -162,11 +187,13 @@ def block_forward(W, x: torch.Tensor, mod: torch.Tensor, cond: torch.Tensor, Bn:
     return sv
 
 
-def block_backward(W, sv, dx: torch.Tensor, dmod: torch.Tensor = None, grads: Dict[str, torch.Tensor] = None):
+def block_backward(W, sv, dx: torch.Tensor, dmod: torch.Tensor = None, grads: Dict[str, torch.Tensor] = None, dxb: torch.Tensor = None):
     """dx [M, 512] f32 = gradient w.r.t. the block's output; on return it holds the gradient w.r.t. its input.
     ``dmod`` (same shape AND strides as the ``mod`` given to block_forward, accumulated into) and ``grads`` (fp32
     destinations keyed like ``prepare_block_weights``, accumulated into - e.g. views of the flat gradient) are
-    allocated when omitted.  Returns (grads, dmod, dcond [Bn*T, Cd] f32)."""
+    allocated when omitted.  ``dxb`` (optional): a bf16 [M, 512] buffer that holds bf16(dx) on entry and on return (every
+    LayerNorm backward of the block writes it beside dx, so no separate cast pass runs between the sub-blocks; the caller hands
+    the same buffer from block to block).  Returns (grads, dmod, dcond [Bn*T, Cd] f32)."""
     Bn, NL, H, T, mod, cond = sv["Bn"], sv["NL"], sv["H"], sv["T"], sv["mod"], sv["cond"]
     D, M, dev = H * HEAD, Bn * NL, dx.device
     G: Dict[str, torch.Tensor] = grads if grads is not None else {}
@@ -186,17 +213,18 @@ def block_backward(W, sv, dx: torch.Tensor, dmod: torch.Tensor = None, grads: Di
             G[bias] = zeros(dy.shape[1])
         lin_wgrad(dy, x_in, G[name], G[bias] if bias is not None else None)
 
+    if dxb is None:
+        dxb = cast_bf16(dx)
+
     def ada_bwd(j, x_saved, dh):
-        ln_mod_bwd(x_saved, dh, mod[:, j, :D], ms, NL, 1.0, dx, dmod[:, j, :D], dmod[:, j, D:])
+        ln_mod_bwd(x_saved, dh, mod[:, j, :D], ms, NL, 1.0, dx, dmod[:, j, :D], dmod[:, j, D:], dx_bf16=dxb)
 
     # ---- feed-forward: x3 = x2 + hid.W2^T + b2 --------------------------------------------------------
-    dxb = cast_bf16(dx)
     lin_bwd(dxb, sv["hid"], "w2", "b2")
     du = geglu_bwd(sv["u"], op_gemm_nt(dxb, W["w2T"]))                              # [M, 4096]
     lin_bwd(du, sv["h3"], "w1", "b1")
     ada_bwd(2, sv["x2"], op_gemm_nt(du, W["w1T"], epilogue=1))
     # ---- cross-attention: x2 = x1 + o2.Wo2^T + bo2 ---------------------------------------------------
-    dxb = cast_bf16(dx)
     lin_bwd(dxb, sv["o2"], "o2", "bo2")
     dO2 = op_gemm_nt(dxb, W["o2T"])
     dq2 = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
@@ -209,7 +237,6 @@ def block_backward(W, sv, dx: torch.Tensor, dmod: torch.Tensor = None, grads: Di
     op_gemm_nt(dvc, W["v2T"], epilogue=2, C_inout=dcond)
     ada_bwd(1, sv["x1"], op_gemm_nt(dq2, W["q2T"], epilogue=1))
     # ---- self-attention: x1 = x0 + o1.Wo^T + bo ------------------------------------------------------
-    dxb = cast_bf16(dx)
     lin_bwd(dxb, sv["o1"], "o", "bo")
     dO1 = op_gemm_nt(dxb, W["oT"])
     qkv = sv["qkv"]
