@@ -290,6 +290,16 @@ int rald_op_gemm_tn(const void* A_bf16, int64_t lda, const void* B_bf16, int64_t
  * of dy.  dy [B*OD*OH*OW][Cout] bf16, x [B][ID][IH][IW][Cin] bf16 channels-last, OD = ID / stride ... */
 int rald_op_conv3d_wgrad(const void* dy_bf16, const void* x_bf16, float* dW, float* dbias, int32_t B, int32_t ID, int32_t IH, int32_t IW, int32_t Cin,
                          int32_t Cout, int32_t stride, int32_t pad, void* stream);
+/* The two weight-gradient products above without atomics: with a caller-owned workspace of _workspace_bytes(...) bytes (16-byte aligned; 0 =
+ * this shape keeps the atomic form and the workspace may be null) every row / voxel range stores its partial result there and a second launch
+ * adds the ranges IN ORDER into C / dW (and colsum / dbias): bit-reproducible run to run, and several times faster for the convolution below
+ * full resolution, whose atomics scatter over the parameter's tap-innermost layout. */
+int64_t rald_op_gemm_tn_workspace_bytes(int32_t M, int32_t N1, int32_t N2);
+int rald_op_gemm_tn_ws(const void* A_bf16, int64_t lda, const void* B_bf16, int64_t ldb, float* C, int64_t ldc, float* colsum, int32_t M, int32_t N1,
+                       int32_t N2, void* workspace, int64_t workspace_bytes, void* stream);
+int64_t rald_op_conv3d_wgrad_workspace_bytes(int32_t B, int32_t ID, int32_t IH, int32_t IW, int32_t Cin, int32_t Cout, int32_t stride, int32_t pad);
+int rald_op_conv3d_wgrad_ws(const void* dy_bf16, const void* x_bf16, float* dW, float* dbias, int32_t B, int32_t ID, int32_t IH, int32_t IW, int32_t Cin,
+                            int32_t Cout, int32_t stride, int32_t pad, void* workspace, int64_t workspace_bytes, void* stream);
 /* conv_in (one input channel) weight gradient, first half: the 27-neighbourhood of channel 0 of cube [B][D][H][W][cube_ch] fp32 per voxel as one
  * bf16 row of 32 (taps kd*9 + kh*3 + kw, zero outside the volume, 5 zero pads); dW = rald_op_gemm_tn(dy, patches). */
 int rald_op_patches27(const float* cube, int32_t cube_ch, void* out_bf16, int32_t B, int32_t D, int32_t H, int32_t W, void* stream);

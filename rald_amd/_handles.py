@@ -230,14 +230,21 @@ def op_gemm_nt(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = 
     return out
 
 
-def op_gemm_tn(A: torch.Tensor, B: torch.Tensor, C_inout: torch.Tensor, colsum: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """C_inout [N1,N2] f32 += A^T.B for row-major bf16 A [M,N1], B [M,N2] (column slices allowed); colsum [N1] f32 += column sums of A."""
+def op_gemm_tn(A: torch.Tensor, B: torch.Tensor, C_inout: torch.Tensor, colsum: Optional[torch.Tensor] = None, atomics: bool = True) -> torch.Tensor:
+    """C_inout [N1,N2] f32 += A^T.B for row-major bf16 A [M,N1], B [M,N2] (column slices allowed); colsum [N1] f32 += column sums of A.
+    atomics=False: the row ranges meet in a workspace and are added in order by a second launch (bit-reproducible)."""
     M, N1 = A.shape
     N2 = B.shape[1]
     assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and C_inout.dtype == torch.float32 and B.shape[0] == M
     assert A.stride(1) == 1 and B.stride(1) == 1 and C_inout.stride(1) == 1 and C_inout.shape == (N1, N2)
-    check(lib().rald_op_gemm_tn(C.c_void_p(_ptr(A)), A.stride(0), C.c_void_p(_ptr(B)), B.stride(0), C.c_void_p(_ptr(C_inout)), C_inout.stride(0),
-                                C.c_void_p(_ptr(colsum) if colsum is not None else 0), M, N1, N2, C.c_void_p(_stream())))
+    if atomics:
+        check(lib().rald_op_gemm_tn(C.c_void_p(_ptr(A)), A.stride(0), C.c_void_p(_ptr(B)), B.stride(0), C.c_void_p(_ptr(C_inout)), C_inout.stride(0),
+                                    C.c_void_p(_ptr(colsum) if colsum is not None else 0), M, N1, N2, C.c_void_p(_stream())))
+        return C_inout
+    nbytes = lib().rald_op_gemm_tn_workspace_bytes(M, N1, N2)
+    ws = torch.empty(max(nbytes, 16), device=A.device, dtype=torch.uint8)
+    check(lib().rald_op_gemm_tn_ws(C.c_void_p(_ptr(A)), A.stride(0), C.c_void_p(_ptr(B)), B.stride(0), C.c_void_p(_ptr(C_inout)), C_inout.stride(0),
+                                   C.c_void_p(_ptr(colsum) if colsum is not None else 0), M, N1, N2, C.c_void_p(_ptr(ws)), nbytes, C.c_void_p(_stream())))
     return C_inout
 
 

@@ -127,6 +127,11 @@ SIGNATURES = {
     "rald_op_ae_decode_tables": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rald_op_gemm_tn": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_void_p]),
     "rald_op_conv3d_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rald_op_gemm_tn_workspace_bytes": (c_i64, [c_int, c_int, c_int]),
+    "rald_op_gemm_tn_ws": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_int, c_int, c_void_p, c_i64, c_void_p]),
+    "rald_op_conv3d_wgrad_workspace_bytes": (c_i64, [c_int] * 8),
+    "rald_op_conv3d_wgrad_ws": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_i64,
+                                        c_void_p]),
     "rald_op_patches27": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "rald_op_proj_in": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "rald_op_final_norm_proj": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),

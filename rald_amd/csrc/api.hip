@@ -317,6 +317,19 @@ int rald_op_conv3d_wgrad(const void* dy_bf16, const void* x_bf16, float* dW, flo
                          int32_t Cout, int32_t stride, int32_t pad, void* stream) {
     return conv3d_wgrad_tn((const bf16*)dy_bf16, (const bf16*)x_bf16, dW, dbias, B, ID, IH, IW, Cin, Cout, stride, pad, (hipStream_t)stream);
 }
+int64_t rald_op_gemm_tn_workspace_bytes(int32_t M, int32_t N1, int32_t N2) { return 4 * gemm_tn_workspace_floats(M, N1, N2); }
+int rald_op_gemm_tn_ws(const void* A_bf16, int64_t lda, const void* B_bf16, int64_t ldb, float* C, int64_t ldc, float* colsum, int32_t M, int32_t N1,
+                       int32_t N2, void* workspace, int64_t workspace_bytes, void* stream) {
+    return gemm_tn((const bf16*)A_bf16, lda, (const bf16*)B_bf16, ldb, C, ldc, colsum, M, N1, N2, (hipStream_t)stream, (float*)workspace, workspace_bytes / 4);
+}
+int64_t rald_op_conv3d_wgrad_workspace_bytes(int32_t B, int32_t ID, int32_t IH, int32_t IW, int32_t Cin, int32_t Cout, int32_t stride, int32_t pad) {
+    return 4 * conv3d_wgrad_workspace_floats(B, ID, IH, IW, Cin, Cout, stride, pad);
+}
+int rald_op_conv3d_wgrad_ws(const void* dy_bf16, const void* x_bf16, float* dW, float* dbias, int32_t B, int32_t ID, int32_t IH, int32_t IW, int32_t Cin,
+                            int32_t Cout, int32_t stride, int32_t pad, void* workspace, int64_t workspace_bytes, void* stream) {
+    return conv3d_wgrad_tn((const bf16*)dy_bf16, (const bf16*)x_bf16, dW, dbias, B, ID, IH, IW, Cin, Cout, stride, pad, (hipStream_t)stream, (float*)workspace,
+                           workspace_bytes / 4);
+}
 int rald_op_patches27(const float* cube, int32_t cube_ch, void* out_bf16, int32_t B, int32_t D, int32_t H, int32_t W, void* stream) {
     return patches27(cube, cube_ch, (bf16*)out_bf16, B, D, H, W, (hipStream_t)stream);
 }

@@ -28,6 +28,9 @@ struct GemmTnArgs {
     const bf16* B; int64_t ldb;      // [M][N2]
     float* C; int64_t ldc;           // [N1][N2] fp32, accumulated into
     float* colsum;                   // optional [N1]: += sum_m A[m][n1] (the bias gradient of the same Linear)
+    // slab form (no atomics, bit-reproducible): row range r writes its partial C to slab[r][N1][N2] and its column sums to slab_b[r][N1]
+    // with plain stores; tn_reduce_kernel adds the ranges in order into C / colsum.  null = the atomic form.
+    float* slab; float* slab_b;
     int M, N1, N2, rows_per_split;
     int t1, t2;                      // 128-wide tiles along n1, n2 (1-D launch: see the kernel)
     // CONV form (weight gradient of a 3x3x3 Conv3d, channels-last input x [B][ID][IH][IW][Cin]): row m = output voxel, column
@@ -169,6 +172,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
         for (int e = 0; e < 4; ++e) {
             const int n1 = n1_0 + n1_w + 16 * i + 4 * rq + e;
             if (n1 >= a.N1) continue;
+            if (a.slab) {                                        // (NARROW: the two wave rows hold partial sums of the same outputs - atomic form only)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n2 = n2_0 + 64 * wb + 16 * j + cl;
+                    if (n2 < a.N2) a.slab[((int64_t)split_ * a.N1 + n1) * a.N2 + n2] = acc[i][j][e];
+                }
+                if (want_cs && cl == 0) a.slab_b[(int64_t)split_ * a.N1 + n1] = csum[i][e];
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n2 = n2_0 + 64 * wb + 16 * j + cl;
@@ -193,6 +205,7 @@ struct WgradLineArgs {
     const bf16* dy; const bf16* x; float* dW; float* dbias;
     int D, H, W, lw, lh, ld, Cin, Cout, lines, steps_per_split, nsteps;   // OUTPUT dims; lines = B*D*H; a step = 64 / W lines; lh / ld = log2(H), log2(D) or -1
     int tiles;                                                            // 64 x 64 blocks of the parameter
+    float* slab; float* slab_b;                                           // slab form (see GemmTnArgs): slab[range][Cout][27][Cin], slab_b[range][Cout]
     int ablate;                                                           // probe builds (RALD_WGRAD_ABLATE): 1 no MFMA, 2 no LDS reads, 4 no DMA after the first stage, 8 no atomics
 };
 
@@ -354,6 +367,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_line_kernel(WgradLineArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int co = co0 + 32 * wa + 16 * i + 4 * kq + e;
+            if (a.slab) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float* dst = a.slab + (((int64_t)split * a.Cout + co) * 27 + kd * 9 + kh * 3) * a.Cin + ci0 + 32 * wb + 16 * j + cl;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) dst[(int64_t)t * a.Cin] = acc[t][i][j][e];
+                }
+                if (want_cs && cl == 0) a.slab_b[(int64_t)split * a.Cout + co] = csum[i][e];
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int ci = ci0 + 32 * wb + 16 * j + cl;
@@ -365,80 +388,165 @@ __global__ __launch_bounds__(256) void conv_wgrad_line_kernel(WgradLineArgs a) {
         }
 }
 
-static int tn_launch(GemmTnArgs a, bool conv, hipStream_t st) {
-    const int t1 = cdiv(a.N1, 128), t2 = cdiv(a.N2, 128);
-    // row ranges: a multiple of 8 (one per XCD), ~1024 workgroups, at least 256 rows (4 k-steps) per range
+// C (+)= sum over the row ranges, in order, of slab[r][n1][n2]; CONV: C is the parameter's [Cout][Cin][27], n2 = tap * Cin + ci.
+// One thread per output, reads coalesced along n2 (the slabs are a few MB and sit in L2 / MALL); colsum likewise from slab_b.
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ slab_b, int ranges, int N1, int N2, int Cin,
+                                                        float* __restrict__ C, int64_t ldc, float* __restrict__ colsum) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n = (int64_t)N1 * N2;
+    if (idx < n) {
+        float s0 = 0.f, s1 = 0.f;
+        int r = 0;
+        for (; r + 2 <= ranges; r += 2) { s0 += slab[(int64_t)r * n + idx]; s1 += slab[(int64_t)(r + 1) * n + idx]; }
+        if (r < ranges) s0 += slab[(int64_t)r * n + idx];
+        const int n1 = (int)(idx / N2), n2 = (int)(idx - (int64_t)n1 * N2);
+        if (Cin > 0) { const int tap = n2 / Cin, ci = n2 - tap * Cin; C[(int64_t)n1 * ldc + ci * 27 + tap] += s0 + s1; }
+        else C[(int64_t)n1 * ldc + n2] += s0 + s1;
+    }
+    if (colsum && idx < N1) {
+        float s = 0.f;
+        for (int r = 0; r < ranges; ++r) s += slab_b[(int64_t)r * N1 + idx];
+        colsum[idx] += s;
+    }
+}
+static int tn_reduce(const float* slab, const float* slab_b, int ranges, int N1, int N2, int Cin, float* C, int64_t ldc, float* colsum, hipStream_t st) {
+    const int64_t n = (int64_t)N1 * N2;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, slab_b, ranges, N1, N2, Cin, C, ldc, colsum);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
+// row ranges of the generic kernel: a multiple of 8 (one per XCD), ~1024 workgroups, at least 256 rows (4 k-steps) per range
+static void tn_ranges(int M, int N1, int N2, int& rows, int& used, int& launched) {
+    const int t1 = cdiv(N1, 128), t2 = cdiv(N2, 128);
     int splits = cdiv(1024, t1 * t2);
-    const int max_splits = cdiv(a.M, 256);
+    const int max_splits = cdiv(M, 256);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
-    const int rows = (int)round_up(cdiv(a.M, splits), 64);
-    splits = (int)round_up(cdiv(a.M, rows), 8);                  // (ranges past the last row return at once)
+    rows = (int)round_up(cdiv(M, splits), 64);
+    used = cdiv(M, rows);
+    launched = (int)round_up(used, 8);                          // (ranges past the last row return at once)
+}
+
+static int tn_launch(GemmTnArgs a, bool conv, hipStream_t st, float* workspace = nullptr) {
+    const int t1 = cdiv(a.N1, 128), t2 = cdiv(a.N2, 128);
+    int rows, used, splits;
+    tn_ranges(a.M, a.N1, a.N2, rows, used, splits);
     RALD_CHECK((int64_t)t1 * t2 * splits < ((int64_t)1 << 31), "gemm_tn: grid too large");
     a.rows_per_split = rows; a.t1 = t1; a.t2 = t2;
     const dim3 grid((unsigned)(t1 * t2 * splits));
     const bool narrow = a.N1 <= 64;
+    a.slab = nullptr; a.slab_b = nullptr;
+    float* C = a.C; float* colsum = a.colsum;
+    if (workspace && !narrow) {                                  // slab form: partials per row range, summed in order afterwards
+        a.slab = workspace;
+        a.slab_b = workspace + (int64_t)used * a.N1 * a.N2;
+    }
     if (conv && narrow) hipLaunchKernelGGL((gemm_tn_kernel<true, true>), grid, dim3(256), 0, st, a);
     else if (conv) hipLaunchKernelGGL((gemm_tn_kernel<true, false>), grid, dim3(256), 0, st, a);
     else if (narrow) hipLaunchKernelGGL((gemm_tn_kernel<false, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((gemm_tn_kernel<false, false>), grid, dim3(256), 0, st, a);
     RALD_HIP(hipGetLastError());
+    if (a.slab) return tn_reduce(a.slab, a.slab_b, used, a.N1, a.N2, conv ? a.Cin : 0, C, a.ldc, colsum, st);
     return 0;
 }
 
-int gemm_tn(const bf16* A, int64_t lda, const bf16* B, int64_t ldb, float* C, int64_t ldc, float* colsum, int M, int N1, int N2, hipStream_t st) {
+int64_t gemm_tn_workspace_floats(int M, int N1, int N2) {
+    if (M < 1 || N1 <= 64 || N2 < 8) return 0;                  // the narrow form keeps its atomics
+    int rows, used, launched;
+    tn_ranges(M, N1, N2, rows, used, launched);
+    return (int64_t)used * ((int64_t)N1 * N2 + N1);
+}
+int gemm_tn(const bf16* A, int64_t lda, const bf16* B, int64_t ldb, float* C, int64_t ldc, float* colsum, int M, int N1, int N2, hipStream_t st,
+            float* workspace, int64_t workspace_floats) {
     RALD_CHECK(A && B && C && M >= 1 && N1 >= 8 && N2 >= 8, "gemm_tn: bad arguments");
     RALD_CHECK(lda % 8 == 0 && ldb % 8 == 0 && lda >= N1 && ldb >= N2 && ldc >= N2, "gemm_tn: leading dimensions (16-byte rows)");
     RALD_CHECK(N1 % 8 == 0 && N2 % 8 == 0, "gemm_tn: N1, N2 must be multiples of 8");
     RALD_CHECK((uintptr_t)A % 16 == 0 && (uintptr_t)B % 16 == 0, "gemm_tn: 16-byte alignment");
     GemmTnArgs a = {};
     a.A = A; a.lda = lda; a.B = B; a.ldb = ldb; a.C = C; a.ldc = ldc; a.colsum = colsum; a.M = M; a.N1 = N1; a.N2 = N2;
-    return tn_launch(a, false, st);
+    const int64_t need = gemm_tn_workspace_floats(M, N1, N2);
+    if (workspace) RALD_CHECK(workspace_floats >= need && (uintptr_t)workspace % 16 == 0, "gemm_tn: workspace smaller than gemm_tn_workspace_floats");
+    return tn_launch(a, false, st, need > 0 ? workspace : nullptr);
 }
 
 // dW [Cout][Cin][27] += sum over output voxels of dy[v][co] . x[v + offset(tap)][ci];  dbias [Cout] += column sums of dy.
 // dy [B*OD*OH*OW][Cout] bf16, x [B][ID][IH][IW][Cin] bf16 (channels-last), OD = ID / stride etc. (3x3x3 kernel).
+// workspace (conv3d_wgrad_workspace_floats floats, or null): the voxel ranges leave their partial gradients there with plain stores and a
+// second launch adds them, in order, into dW / dbias - bit-reproducible, and 4-13 x faster below full resolution: the atomic form ends every
+// workgroup in 12 288 atomics whose 64 lanes hit 64 different cache lines (the parameter layout puts the 27 taps innermost), which at
+// 32 x 16 x 8 voxels was 93 % of the launch (928 -> 70 us without them, tools/bench_wgrad_levels.py).  null = the atomic form.
+namespace {
+struct WgradPlan { bool line; int splits, used, steps_per_split, nsteps, tiles, lw, lh, ld; };
+int lg2_exact(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; }
+WgradPlan wgrad_plan(int B, int ID, int IH, int IW, int Cin, int Cout, int stride, int pad) {
+    WgradPlan p = {};
+    const int OD = ID / stride, OH = IH / stride, OW = IW / stride;
+    const bool s1 = stride == 1 && pad == 1, s2 = stride == 2 && pad == 0 && ID % 2 == 0 && IH % 2 == 0 && IW % 2 == 0;
+    p.lw = lg2_exact(OW); p.lh = lg2_exact(OH); p.ld = lg2_exact(OD);
+    p.line = (s1 || s2) && Cin % 64 == 0 && Cout % 64 == 0 && p.lw >= 2 && OW <= 64 && ((int64_t)B * OD * OH) % (64 / OW) == 0 &&
+             (int64_t)B * OD * OH < ((int64_t)1 << 30);
+    if (p.line) {
+        p.nsteps = B * OD * OH / (64 / OW);
+        p.tiles = (Cin / 64) * (Cout / 64);
+        // Line ranges: a multiple of 8 (one per XCD and slot round), chosen so that the workgroups fill whole rounds of the chip's 512 slots
+        // (2 per CU) - 1 080 workgroups ran as two rounds and a third one 11 % full - and as few as that allows (every range ends in a
+        // 64 x 64 x 3 block of partial sums per workgroup)
+        int splits = 8;
+        double best = -1.0;
+        const int forced = RALD_PROBE_ENV("RALD_WGRAD_SPLITS", 0);
+        for (int r = 1; r <= 4; ++r) {
+            int sp = 8 * ((512 * r) / (72 * p.tiles));
+            if (sp < 8) sp = 8;
+            if (sp > (int)round_up(cdiv(p.nsteps, 8), 8)) sp = (int)round_up(cdiv(p.nsteps, 8), 8);
+            const int wgs = 9 * p.tiles * sp;
+            const double eff = (double)wgs / (double)(cdiv(wgs, 512) * 512);
+            if (eff > best + 0.05) { best = eff; splits = sp; }
+        }
+        if (forced > 0) splits = (int)round_up(forced, 8);
+        p.steps_per_split = cdiv(p.nsteps, splits);
+        p.used = cdiv(p.nsteps, p.steps_per_split);
+        p.splits = (int)round_up(p.used, 8);                     // (ranges past the last step return at once)
+    } else {
+        int rows;
+        tn_ranges(B * OD * OH * OW, Cout, 27 * Cin, rows, p.used, p.splits);
+    }
+    return p;
+}
+}  // namespace
+
+int64_t conv3d_wgrad_workspace_floats(int B, int ID, int IH, int IW, int Cin, int Cout, int stride, int pad) {
+    if (B < 1 || ID < 1 || IH < 1 || IW < 1 || (stride != 1 && stride != 2) || Cin < 8 || Cout < 8) return 0;
+    if ((int64_t)B * (ID / stride) * (IH / stride) * (IW / stride) >= ((int64_t)1 << 31)) return 0;
+    if (Cout <= 64 && !wgrad_plan(B, ID, IH, IW, Cin, Cout, stride, pad).line) return 0;     // the narrow generic form keeps its atomics
+    const WgradPlan p = wgrad_plan(B, ID, IH, IW, Cin, Cout, stride, pad);
+    return (int64_t)p.used * ((int64_t)Cout * 27 * Cin + Cout);
+}
+
 int conv3d_wgrad_tn(const bf16* dy, const bf16* x, float* dW, float* dbias, int B, int ID, int IH, int IW, int Cin, int Cout, int stride, int pad,
-                    hipStream_t st) {
+                    hipStream_t st, float* workspace, int64_t workspace_floats) {
     RALD_CHECK(dy && x && dW && B >= 1 && ID >= 1 && IH >= 1 && IW >= 1 && (stride == 1 || stride == 2) && pad >= 0, "conv3d_wgrad_tn: bad arguments");
     RALD_CHECK(Cin % 8 == 0 && Cout % 8 == 0, "conv3d_wgrad_tn: channel counts must be multiples of 8");
     RALD_CHECK((uintptr_t)dy % 16 == 0 && (uintptr_t)x % 16 == 0, "conv3d_wgrad_tn: 16-byte alignment");
     const int OD = ID / stride, OH = IH / stride, OW = IW / stride;
     const int64_t M = (int64_t)B * OD * OH * OW;
     RALD_CHECK(M >= 1 && M < ((int64_t)1 << 31) && (int64_t)B * ID * IH * IW * Cin < ((int64_t)1 << 40), "conv3d_wgrad_tn: volume too large");
-    auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
-    const bool s1 = stride == 1 && pad == 1, s2 = stride == 2 && pad == 0 && ID % 2 == 0 && IH % 2 == 0 && IW % 2 == 0;
-    if ((s1 || s2) && Cin % 64 == 0 && Cout % 64 == 0 && lg(OW) >= 2 && OW <= 64 && ((int64_t)B * OD * OH) % (64 / OW) == 0 &&
-        (int64_t)B * OD * OH < ((int64_t)1 << 30)) {
+    const WgradPlan p = wgrad_plan(B, ID, IH, IW, Cin, Cout, stride, pad);
+    const int64_t need = conv3d_wgrad_workspace_floats(B, ID, IH, IW, Cin, Cout, stride, pad);
+    if (workspace) RALD_CHECK(workspace_floats >= need && (uintptr_t)workspace % 16 == 0, "conv3d_wgrad_tn: workspace smaller than conv3d_wgrad_workspace_floats");
+    if (need == 0) workspace = nullptr;
+    if (p.line) {
         WgradLineArgs w;
-        w.dy = dy; w.x = x; w.dW = dW; w.dbias = dbias; w.D = OD; w.H = OH; w.W = OW; w.lw = lg(OW); w.Cin = Cin; w.Cout = Cout;
-        w.lh = lg(OH); w.ld = lg(OD);
+        w.dy = dy; w.x = x; w.dW = dW; w.dbias = dbias; w.D = OD; w.H = OH; w.W = OW; w.lw = p.lw; w.Cin = Cin; w.Cout = Cout;
+        w.lh = p.lh; w.ld = p.ld;
         if (w.lh < 0 || w.ld < 0) w.lh = w.ld = -1;
         w.lines = B * OD * OH;
-        w.nsteps = w.lines / (64 / OW);
-        const int tiles = (Cin / 64) * (Cout / 64);
-        // Line ranges: a multiple of 8 (one per XCD and slot round), chosen so that the workgroups fill whole rounds of the chip's 512 slots
-        // (2 per CU) - 1 080 workgroups ran as two rounds and a third one 11 % full - and as few as that allows: every range ends in
-        // 64 x 64 x 3 atomics per workgroup (measured: a quarter of the kernel's time at 120 ranges).
-        int splits = 8;
-        {
-            double best = -1.0;
-            const int forced = RALD_PROBE_ENV("RALD_WGRAD_SPLITS", 0);
-            for (int r = 1; r <= 4; ++r) {
-                int sp = 8 * ((512 * r) / (72 * tiles));
-                if (sp < 8) sp = 8;
-                if (sp > (int)round_up(cdiv(w.nsteps, 8), 8)) sp = (int)round_up(cdiv(w.nsteps, 8), 8);
-                const int wgs = 9 * tiles * sp;
-                const double eff = (double)wgs / (double)(cdiv(wgs, 512) * 512);
-                if (eff > best + 0.05) { best = eff; splits = sp; }
-            }
-            if (forced > 0) splits = (int)round_up(forced, 8);
-        }
-        w.steps_per_split = cdiv(w.nsteps, splits);
-        splits = (int)round_up(cdiv(w.nsteps, w.steps_per_split), 8);          // (ranges past the last step return at once)
-        w.tiles = tiles;
+        w.nsteps = p.nsteps;
+        w.steps_per_split = p.steps_per_split;
+        w.tiles = p.tiles;
+        w.slab = workspace; w.slab_b = workspace ? workspace + (int64_t)p.used * Cout * 27 * Cin : nullptr;
         w.ablate = RALD_PROBE_ENV("RALD_WGRAD_ABLATE", 0);
-        RALD_CHECK((int64_t)9 * tiles * splits < ((int64_t)1 << 31), "conv3d_wgrad_tn: grid too large");
+        RALD_CHECK((int64_t)9 * p.tiles * p.splits < ((int64_t)1 << 31), "conv3d_wgrad_tn: grid too large");
         constexpr int LDS1 = 3 * 20 * WL_PIECE, LDS2 = 2 * 28 * WL_PIECE;
         static bool attr_set = false;
         if (!attr_set) {
@@ -446,17 +554,18 @@ int conv3d_wgrad_tn(const bf16* dy, const bf16* x, float* dW, float* dbias, int 
             RALD_HIP(hipFuncSetAttribute((const void*)conv_wgrad_line_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2));
             attr_set = true;
         }
-        if (s1) hipLaunchKernelGGL(conv_wgrad_line_kernel<1>, dim3(9 * tiles * splits), dim3(256), LDS1, st, w);
-        else hipLaunchKernelGGL(conv_wgrad_line_kernel<2>, dim3(9 * tiles * splits), dim3(256), LDS2, st, w);
+        if (stride == 1) hipLaunchKernelGGL(conv_wgrad_line_kernel<1>, dim3(9 * p.tiles * p.splits), dim3(256), LDS1, st, w);
+        else hipLaunchKernelGGL(conv_wgrad_line_kernel<2>, dim3(9 * p.tiles * p.splits), dim3(256), LDS2, st, w);
         RALD_HIP(hipGetLastError());
+        if (workspace) return tn_reduce(w.slab, w.slab_b, p.used, Cout, 27 * Cin, Cin, dW, (int64_t)Cin * 27, dbias, st);
         return 0;
     }
     GemmTnArgs a = {};
     a.A = dy; a.lda = Cout; a.B = x; a.ldb = 0; a.C = dW; a.ldc = (int64_t)Cin * 27; a.colsum = dbias; a.M = (int)M; a.N1 = Cout; a.N2 = 27 * Cin;
     a.ID = ID; a.IH = IH; a.IW = IW; a.Cin = Cin; a.OD = OD; a.OH = OH; a.OW = OW; a.stride = stride; a.pad = pad;
-    a.lw = lg(OW); a.lh = lg(OH); a.ld = lg(OD);
+    a.lw = p.lw; a.lh = p.lh; a.ld = p.ld;
     if (a.lw < 0 || a.lh < 0 || a.ld < 0) a.lw = a.lh = a.ld = -1;
-    return tn_launch(a, true, st);
+    return tn_launch(a, true, st, workspace);
 }
 
 }  // namespace rald

@@ -79,10 +79,13 @@ inline bool gemm_resid_ln_pays(int M, int K = 512) { (void)K; return M >= 16384;
 int patches27(const float* cube, int cube_ch, bf16* out, int B, int D, int H, int Wd, hipStream_t st);
 // ---------------------------------------------------------------- gemm_tn.hip
 // C[n1][n2] += sum_m A[m][n1] . B[m][n2] (fp32, atomics); colsum (optional) [n1] += sum_m A[m][n1].  Weight / bias gradient of a Linear.
-int gemm_tn(const bf16* A, int64_t lda, const bf16* B, int64_t ldb, float* C, int64_t ldc, float* colsum, int M, int N1, int N2, hipStream_t st);
+int gemm_tn(const bf16* A, int64_t lda, const bf16* B, int64_t ldb, float* C, int64_t ldc, float* colsum, int M, int N1, int N2, hipStream_t st,
+            float* workspace = nullptr, int64_t workspace_floats = 0);
+int64_t gemm_tn_workspace_floats(int M, int N1, int N2);
 // the same with B = the virtual patch matrix of a 3x3x3 Conv3d over channels-last x: dW [Cout][Cin][27] += ..., dbias += column sums of dy
 int conv3d_wgrad_tn(const bf16* dy, const bf16* x, float* dW, float* dbias, int B, int ID, int IH, int IW, int Cin, int Cout, int stride, int pad,
-                    hipStream_t st);
+                    hipStream_t st, float* workspace = nullptr, int64_t workspace_floats = 0);
+int64_t conv3d_wgrad_workspace_floats(int B, int ID, int IH, int IW, int Cin, int Cout, int stride, int pad);
 
 // ---------------------------------------------------------------- norm.hip
 // out_bf16[m][c] = LN(x[m])[c] * (add_one + g[s][c]) + b[s][c],  s = (m / rows_per_group) * gstride

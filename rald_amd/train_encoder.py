@@ -105,7 +105,11 @@ def conv_wgrad(dy: torch.Tensor, x16: torch.Tensor, dW: torch.Tensor, dbias: Opt
         dy16 = TO.cast_bf16(dy16.contiguous())
     assert x16.dtype == torch.bfloat16 and x16.is_contiguous() and dW.is_contiguous() and dW.dtype == torch.float32
     assert dy16.shape[0] == B * (ID // stride) * (IH // stride) * (IW // stride)
-    check(lib().rald_op_conv3d_wgrad(_p(dy16), _p(x16), _p(dW), _p(dbias), B, ID, IH, IW, Cin, Cout, stride, pad, _st()))
+    # the voxel ranges meet in a workspace and are summed in order by a second launch (no atomics: bit-reproducible, and 4-13 x faster below
+    # full resolution - csrc/gemm_tn.hip)
+    nbytes = lib().rald_op_conv3d_wgrad_workspace_bytes(B, ID, IH, IW, Cin, Cout, stride, pad)
+    ws = torch.empty(max(nbytes, 16), device=dy16.device, dtype=torch.uint8)
+    check(lib().rald_op_conv3d_wgrad_ws(_p(dy16), _p(x16), _p(dW), _p(dbias), B, ID, IH, IW, Cin, Cout, stride, pad, _p(ws), nbytes, _st()))
 
 
 def _g(p: torch.nn.Parameter) -> torch.Tensor:

@@ -86,7 +86,9 @@ def lin_wgrad(dy: torch.Tensor, x_in: torch.Tensor, dW: torch.Tensor, dbias: tor
         dy = cast_bf16(dy)
     if x_in.dtype != torch.bfloat16:
         x_in = cast_bf16(x_in)
-    op_gemm_tn(dy, x_in, dW, dbias)
+    # large gradients: the row ranges meet in a workspace and are summed in order (no atomics: reproducible, and 59 -> 38 us for ff.net.2 at
+    # 4 096 rows); a 512 x 512 gradient has too few ranges for the extra launch to pay (20.9 vs 24.0 us)
+    op_gemm_tn(dy, x_in, dW, dbias, atomics=dy.shape[1] * x_in.shape[1] < 512 * 1024)
 
 
 def colsum(x: torch.Tensor, out: torch.Tensor) -> None:

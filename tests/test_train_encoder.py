@@ -42,6 +42,41 @@ def test_conv3d_forward_dgrad_wgrad_vs_autograd():
         assert rel_l2(dW.cpu(), Wt.grad) < 1e-2 and rel_l2(db.cpu(), dy.sum((0, 2, 3, 4))) < 5e-3
 
 
+def test_weight_gradients_through_the_workspace_are_bit_reproducible_and_match_the_atomic_form():
+    """conv3d / Linear weight gradients with the row ranges meeting in a workspace (summed in order by a second launch) instead of
+    fp32 atomics: two runs give identical bits, the result accumulates INTO the destination, and it equals the atomic form to fp32
+    summation-order noise (1e-6).  Shapes: line-staged kernel (64 -> 128 at width 8, several 64 x 64 blocks and ranges), generic
+    kernel in its convolution form (width 2) and as the plain row-contracting GEMM."""
+    import ctypes as C
+    from rald_amd import train_encoder as TE
+    from rald_amd._handles import op_gemm_tn
+    from rald_amd._lib import check, lib
+    p = lambda t: C.c_void_p(t.data_ptr() if t is not None else 0)
+    for (B, D, H, W, Cin, Cout) in ((4, 16, 8, 8, 64, 128), (2, 4, 4, 2, 128, 256)):
+        x16 = synth.normal([B, D, H, W, Cin], 620).bfloat16().cuda()
+        dy = synth.normal([B, D, H, W, Cout], 621).bfloat16().cuda()
+        outs = []
+        for _ in range(2):
+            dW, db = torch.full((Cout, Cin, 3, 3, 3), 0.5, device="cuda"), torch.full((Cout,), 0.25, device="cuda")
+            TE.conv_wgrad(dy, x16, dW, db)
+            outs.append((dW, db))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        aW, ab = torch.full((Cout, Cin, 3, 3, 3), 0.5, device="cuda"), torch.full((Cout,), 0.25, device="cuda")
+        check(lib().rald_op_conv3d_wgrad(p(dy), p(x16), p(aW), p(ab), B, D, H, W, Cin, Cout, 1, 1, None))
+        torch.cuda.synchronize()
+        assert rel_l2(outs[0][0].cpu(), aW.cpu()) < 1e-6 and rel_l2(outs[0][1].cpu(), ab.cpu()) < 1e-6
+    A, Bm = synth.normal([1024, 256], 622).bfloat16().cuda(), synth.normal([1024, 384], 623).bfloat16().cuda()
+    res = []
+    for atomics in (False, False, True):
+        Cm, cs = torch.ones(256, 384, device="cuda"), torch.ones(256, device="cuda")
+        op_gemm_tn(A, Bm, Cm, cs, atomics=atomics)
+        res.append((Cm, cs))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert rel_l2(res[0][0].cpu(), res[2][0].cpu()) < 1e-6 and rel_l2(res[0][1].cpu(), res[2][1].cpu()) < 1e-6
+    want = A.float().T @ Bm.float() + 1
+    assert rel_l2(res[0][0].cpu(), want.cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("B,D,H,W,Cc", [(2, 8, 4, 4, 64), (2, 8, 8, 16, 64)])      # output width 2: generic weight-gradient kernel; 8: the line-staged stride-2 form
 def test_downsample_forward_dgrad_wgrad_vs_autograd(B, D, H, W, Cc):
     from rald_amd import train_encoder as TE
