@@ -353,6 +353,14 @@ int rald_op_groupnorm(const float* x, const float* gamma, const float* beta, voi
 /* its backward: da = gradient w.r.t. the (activated) output; dx written or accumulated; dgamma/dbeta accumulated; gsum_scratch [B][32][2] doubles */
 int rald_op_groupnorm_bwd(const float* x, const double* stats, const float* gamma, const float* beta, const float* da, float* dx, float* dgamma,
                           float* dbeta, double* gsum_scratch, int32_t B, int32_t S, int32_t C, int32_t swish, int32_t accumulate, void* stream);
+/* rald_op_groupnorm's normalisation alone, from the [B][32][2] statistics a forward call left (the training backward re-creates activations) */
+int rald_op_groupnorm_apply(const float* x, const double* stats, const float* gamma, const float* beta, void* y_bf16, int32_t B, int32_t S, int32_t C,
+                            int32_t swish, void* stream);
+/* rald_op_groupnorm_bwd that also leaves the resulting dx rounded to bf16 in dx_bf16 (what the convolution gradients of the next layer read);
+ * dx may be null when only the bf16 form is wanted (not with accumulate) */
+int rald_op_groupnorm_bwd_cast(const float* x, const double* stats, const float* gamma, const float* beta, const float* da, float* dx, void* dx_bf16,
+                               float* dgamma, float* dbeta, double* gsum_scratch, int32_t B, int32_t S, int32_t C, int32_t swish, int32_t accumulate,
+                               void* stream);
 /* conv_in (Cin = 1 read in place from channel 0 of the cube) and its weight gradient dW [Cout][27] (accumulated) */
 int rald_op_conv_in(const float* cube, int32_t cube_ch, int32_t Cin, const float* W, const float* bias, float* out, int32_t B, int32_t D, int32_t H,
                     int32_t Wd, int32_t Cout, void* stream);

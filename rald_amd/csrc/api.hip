@@ -402,6 +402,15 @@ int rald_op_groupnorm_bwd(const float* x, const double* stats, const float* gamm
                           float* dbeta, double* gsum_scratch, int32_t B, int32_t S, int32_t C, int32_t swish, int32_t accumulate, void* stream) {
     return groupnorm_bwd(x, stats, gamma, beta, da, dx, dgamma, dbeta, gsum_scratch, B, S, C, swish, accumulate, (hipStream_t)stream);
 }
+int rald_op_groupnorm_apply(const float* x, const double* stats, const float* gamma, const float* beta, void* y_bf16, int32_t B, int32_t S, int32_t C,
+                            int32_t swish, void* stream) {
+    return groupnorm_apply(x, stats, gamma, beta, (bf16*)y_bf16, B, S, C, swish, (hipStream_t)stream);
+}
+int rald_op_groupnorm_bwd_cast(const float* x, const double* stats, const float* gamma, const float* beta, const float* da, float* dx, void* dx_bf16,
+                               float* dgamma, float* dbeta, double* gsum_scratch, int32_t B, int32_t S, int32_t C, int32_t swish, int32_t accumulate,
+                               void* stream) {
+    return groupnorm_bwd(x, stats, gamma, beta, da, dx, dgamma, dbeta, gsum_scratch, B, S, C, swish, accumulate, (hipStream_t)stream, (bf16*)dx_bf16);
+}
 int rald_op_conv_in(const float* cube, int32_t cube_ch, int32_t Cin, const float* W, const float* bias, float* out, int32_t B, int32_t D, int32_t H,
                     int32_t Wd, int32_t Cout, void* stream) {
     return conv_in_fwd(cube, cube_ch, Cin, W, bias, out, B, D, H, Wd, Cout, (hipStream_t)stream);

@@ -1071,6 +1071,17 @@ int groupnorm_fwd(const float* x, const float* gamma, const float* beta, bf16* y
     return 0;
 }
 
+// the normalisation alone from statistics already in hand (the training backward re-creates the activations it did not keep)
+int groupnorm_apply(const float* x, const double* stats, const float* gamma, const float* beta, bf16* y, int B, int S, int C, int swish, hipStream_t st) {
+    RALD_CHECK(x && gamma && beta && y && stats, "groupnorm_apply: null pointer");
+    RALD_CHECK(B > 0 && S > 0 && C % 64 == 0 && 256 % (C / 4) == 0, "groupnorm_apply: channel count must be 64, 128 or 256");
+    const int64_t quads = (int64_t)S * C / 4;
+    const int blocks = (int)((quads + 255) / 256 < 1024 ? (quads + 255) / 256 : 1024);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks, B), dim3(256), 0, st, x, stats, gamma, beta, y, S, C, 1e-6f, swish ? 1 : 0);
+    RALD_HIP(hipGetLastError());
+    return 0;
+}
+
 int conv_in_fwd(const float* cube, int cube_ch, int Cin, const float* W, const float* bias, float* out, int B, int D, int H, int Wd, int Cout,
                 hipStream_t st) {
     RALD_CHECK(cube && W && bias && out && Cout % 8 == 0 && 256 % (Cout / 8) == 0 && cube_ch >= Cin, "conv_in: bad arguments");

@@ -214,6 +214,7 @@ struct GnBwdArgs {
     const float* x; const double* stats; const float* gamma; const float* beta; const float* da;
     float* dx; float* dgamma; float* dbeta; double* gsum;
     int S, C, swish, accumulate; float eps;
+    bf16* dxb;                                              // optional: the (accumulated) dx rounded to bf16 - what the convolution gradients read; dx may then be null
 };
 __device__ __forceinline__ float gn_dy(float yv, float da, int swish) {
     if (!swish) return da;
@@ -258,10 +259,14 @@ __global__ __launch_bounds__(256) void gn_bwd_pass_kernel(GnBwdArgs a, int pass,
             else o[j] = srstd[g] * (dy * gg[j] - sm1[g] - xh * sm2[g]);
         }
         if (pass == 2) {
-            float4* dst = reinterpret_cast<float4*>(a.dx) + idx;
-            float4 r = a.accumulate ? *dst : make_float4(0.f, 0.f, 0.f, 0.f);
-            r.x += o[0]; r.y += o[1]; r.z += o[2]; r.w += o[3];
-            *dst = r;
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.dx) {
+                float4* dst = reinterpret_cast<float4*>(a.dx) + idx;
+                if (a.accumulate) r = *dst;
+                r.x += o[0]; r.y += o[1]; r.z += o[2]; r.w += o[3];
+                *dst = r;
+            } else { r.x = o[0]; r.y = o[1]; r.z = o[2]; r.w = o[3]; }
+            if (a.dxb) reinterpret_cast<bf16x4*>(a.dxb)[idx] = pack4(r.x, r.y, r.z, r.w);
         }
     }
     if (pass == 2) return;
@@ -281,12 +286,14 @@ __global__ __launch_bounds__(256) void gn_bwd_pass_kernel(GnBwdArgs a, int pass,
     }
 }
 int groupnorm_bwd(const float* x, const double* stats, const float* gamma, const float* beta, const float* da, float* dx, float* dgamma, float* dbeta,
-                  double* gsum_scratch, int B, int S, int C, int swish, int accumulate, hipStream_t st) {
-    RALD_CHECK(x && stats && gamma && beta && da && dx && dgamma && dbeta && gsum_scratch, "groupnorm_bwd: null pointer");
+                  double* gsum_scratch, int B, int S, int C, int swish, int accumulate, hipStream_t st, bf16* dx_bf16) {
+    RALD_CHECK(x && stats && gamma && beta && da && (dx || dx_bf16) && dgamma && dbeta && gsum_scratch, "groupnorm_bwd: null pointer");
+    RALD_CHECK(dx || !accumulate, "groupnorm_bwd: accumulating needs the fp32 dx");
+    RALD_CHECK((uintptr_t)dx_bf16 % 8 == 0, "groupnorm_bwd: the bf16 copy must be 8-byte aligned");
     RALD_CHECK(B > 0 && S > 0 && C % 64 == 0 && C <= 256 && 256 % (C / 4) == 0, "groupnorm_bwd: channel count must be 64, 128 or 256");
     GnBwdArgs a;
     a.x = x; a.stats = stats; a.gamma = gamma; a.beta = beta; a.da = da; a.dx = dx; a.dgamma = dgamma; a.dbeta = dbeta; a.gsum = gsum_scratch;
-    a.S = S; a.C = C; a.swish = swish; a.accumulate = accumulate; a.eps = 1e-6f;
+    a.S = S; a.C = C; a.swish = swish; a.accumulate = accumulate; a.eps = 1e-6f; a.dxb = dx_bf16;
     RALD_HIP(hipMemsetAsync(gsum_scratch, 0, (size_t)B * 32 * 2 * 8, st));
     const int vpb = 1024;
     hipLaunchKernelGGL(gn_bwd_pass_kernel, dim3(cdiv(S, vpb), B), dim3(256), 0, st, a, 1, vpb);

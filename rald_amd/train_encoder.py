@@ -62,12 +62,26 @@ def groupnorm(x: torch.Tensor, gamma, beta, swish: bool):
     return y, buf[:B * 64].view(B, 32, 2)
 
 
-def groupnorm_bwd(x, stats, gamma, beta, da, dx, dgamma, dbeta, swish: bool, accumulate: bool):
+def groupnorm_apply(x: torch.Tensor, stats: torch.Tensor, gamma, beta, swish: bool) -> torch.Tensor:
+    """The normalisation alone from the statistics ``groupnorm`` returned (the backward pass re-creates the activations it did not keep)."""
+    B, Cc = x.shape[0], x.shape[-1]
+    S = x.numel() // (B * Cc)
+    y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    check(lib().rald_op_groupnorm_apply(_p(x), _p(stats), _p(gamma), _p(beta), _p(y), B, S, Cc, int(swish), _st()))
+    return y
+
+
+def groupnorm_bwd(x, stats, gamma, beta, da, dx, dgamma, dbeta, swish: bool, accumulate: bool, dx_bf16: Optional[torch.Tensor] = None):
+    """dx (fp32, may be None when only ``dx_bf16`` is wanted) written or accumulated; dx_bf16 (optional) = the resulting dx rounded to bf16."""
     B, Cc = x.shape[0], x.shape[-1]
     S = x.numel() // (B * Cc)
     scratch = torch.empty(B, 32, 2, device=x.device, dtype=torch.float64)
-    check(lib().rald_op_groupnorm_bwd(_p(x), _p(stats), _p(gamma), _p(beta), _p(da), _p(dx), _p(dgamma), _p(dbeta), _p(scratch), B, S, Cc,
-                                      int(swish), int(accumulate), _st()))
+    if dx_bf16 is None:
+        check(lib().rald_op_groupnorm_bwd(_p(x), _p(stats), _p(gamma), _p(beta), _p(da), _p(dx), _p(dgamma), _p(dbeta), _p(scratch), B, S, Cc,
+                                          int(swish), int(accumulate), _st()))
+    else:
+        check(lib().rald_op_groupnorm_bwd_cast(_p(x), _p(stats), _p(gamma), _p(beta), _p(da), _p(dx), _p(dx_bf16), _p(dgamma), _p(dbeta), _p(scratch),
+                                               B, S, Cc, int(swish), int(accumulate), _st()))
 
 
 def _zero_bias(n, dev):
@@ -80,8 +94,11 @@ def conv_dgrad(dy: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
     cpad = -(-Cout // 64) * 64
     B = dy.shape[0]
     M = dy.numel() // Cout
-    dy16 = torch.empty(*dy.shape[:-1], cpad, device=dy.device, dtype=torch.bfloat16)
-    check(lib().rald_op_pad_channels(_p(dy), _p(dy16), M, Cout, cpad, _st()))
+    if dy.dtype == torch.bfloat16 and cpad == Cout:
+        dy16 = dy.contiguous()                               # already what the convolution reads (the caller's one bf16 copy of dy)
+    else:
+        dy16 = torch.empty(*dy.shape[:-1], cpad, device=dy.device, dtype=torch.bfloat16)
+        check(lib().rald_op_pad_channels(_p(dy.float() if dy.dtype != torch.float32 else dy), _p(dy16), M, Cout, cpad, _st()))
     return conv3d(dy16, pack_conv(W, dgrad=True, pad_to=cpad), _zero_bias(Cin, dy.device), None, 1, 1)
 
 
@@ -160,29 +177,38 @@ class EncoderTrainer:
         self.saved.append(("res", name, cin, cout, x, st1, t1, st2))
         return out
 
-    def _res_bwd(self, rec, dout):
+    def _res_bwd(self, rec, dout, dout16=None):
+        """dout: fp32 gradient w.r.t. the block's output, dout16 its bf16 copy when the producer already made one.  The convolution
+        gradients read bf16: every gradient tensor is rounded ONCE (by the GroupNorm backward that produces it, in the same pass) and
+        that copy feeds both the weight- and the data-gradient convolution; activations are re-created from the saved statistics
+        without a second statistics pass.  Returns (dx fp32, dx bf16)."""
         _, name, cin, cout, x, st1, t1, st2 = rec
         P = lambda n: self.p(name + n)
-        h2, _ = groupnorm(t1, P(".norm2.weight").data, P(".norm2.bias").data, True)
-        conv_wgrad(dout, h2, _g(P(".conv2.weight")), _g(P(".conv2.bias")))
+        if dout16 is None:
+            dout16 = TO.cast_bf16(dout)
+        h2 = groupnorm_apply(t1, st2, P(".norm2.weight").data, P(".norm2.bias").data, True)
+        conv_wgrad(dout16, h2, _g(P(".conv2.weight")), _g(P(".conv2.bias")))
         del h2
-        dh2 = conv_dgrad(dout, P(".conv2.weight").data)
-        dt1 = torch.empty_like(t1)
-        groupnorm_bwd(t1, st2, P(".norm2.weight").data, P(".norm2.bias").data, dh2, dt1, _g(P(".norm2.weight")), _g(P(".norm2.bias")), True, False)
+        dh2 = conv_dgrad(dout16, P(".conv2.weight").data)
+        dt1 = torch.empty(t1.shape, device=t1.device, dtype=torch.bfloat16)                 # consumed by the two convolution gradients only
+        groupnorm_bwd(t1, st2, P(".norm2.weight").data, P(".norm2.bias").data, dh2, None, _g(P(".norm2.weight")), _g(P(".norm2.bias")), True, False,
+                      dx_bf16=dt1)
         del dh2
-        h1, _ = groupnorm(x, P(".norm1.weight").data, P(".norm1.bias").data, True)
+        h1 = groupnorm_apply(x, st1, P(".norm1.weight").data, P(".norm1.bias").data, True)
         conv_wgrad(dt1, h1, _g(P(".conv1.weight")), _g(P(".conv1.bias")))
         del h1
         dh1 = conv_dgrad(dt1, P(".conv1.weight").data)
         if cin == cout:
             dx = dout
         else:
-            d2 = dout.view(-1, cout)
+            d16 = dout16.view(-1, cout)
             W16 = P(".nin_shortcut.weight").data.view(cout, cin).to(torch.bfloat16)
-            dx = op_gemm_nt(TO.cast_bf16(d2), TO.T2(W16), epilogue=1).view(*x.shape)
-            TO.lin_wgrad(d2, TO.cast_bf16(x).view(-1, cin), _g(P(".nin_shortcut.weight")).view(cout, cin), _g(P(".nin_shortcut.bias")))
-        groupnorm_bwd(x, st1, P(".norm1.weight").data, P(".norm1.bias").data, dh1, dx, _g(P(".norm1.weight")), _g(P(".norm1.bias")), True, True)
-        return dx
+            dx = op_gemm_nt(d16, TO.T2(W16), epilogue=1).view(*x.shape)
+            TO.lin_wgrad(d16, TO.cast_bf16(x).view(-1, cin), _g(P(".nin_shortcut.weight")).view(cout, cin), _g(P(".nin_shortcut.bias")))
+        dx16 = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+        groupnorm_bwd(x, st1, P(".norm1.weight").data, P(".norm1.bias").data, dh1, dx, _g(P(".norm1.weight")), _g(P(".norm1.bias")), True, True,
+                      dx_bf16=dx16)
+        return dx, dx16
 
     # ---- AttnBlock :102-135 (single head, S tokens, scale C^-1/2) -----------------------------------------------------
     def _attn_fwd(self, x, name):
@@ -218,7 +244,7 @@ class EncoderTrainer:
         W16 = lambda n: P(n).data.view(Cc, Cc).to(torch.bfloat16)
         scale = float(Cc) ** -0.5
         d2 = dxo.view(B * S, Cc)
-        n16, _ = groupnorm(x, P(".norm.weight").data, P(".norm.bias").data, False)
+        n16 = groupnorm_apply(x, st, P(".norm.weight").data, P(".norm.bias").data, False)
         n2 = n16.view(B * S, Cc)
         do = op_gemm_nt(TO.cast_bf16(d2), TO.T2(W16(".proj_out.weight")))                       # [B*S, C] bf16
         TO.lin_wgrad(d2, o, _g(P(".proj_out.weight")).view(Cc, Cc), _g(P(".proj_out.bias")))
@@ -299,23 +325,23 @@ class EncoderTrainer:
         _sgemm(d2, P["radar_token_project.weight"].data, dz, trans_b=True)                       # dtok . Wp
         _, x, st = self.saved.pop()
         dz5 = dz.view(*x.shape[:-1], dz.shape[-1])
-        h, _ = groupnorm(x, self.w("norm_out.weight"), self.w("norm_out.bias"), True)
+        h = groupnorm_apply(x, st, self.w("norm_out.weight"), self.w("norm_out.bias"), True)
         conv_wgrad(dz5, h, _g(self.p("conv_out.weight")), _g(self.p("conv_out.bias")))
         dh = conv_dgrad(dz5, self.w("conv_out.weight"))
-        dx = torch.empty_like(x)
+        dx, dx16 = torch.empty_like(x), torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
         groupnorm_bwd(x, st, self.w("norm_out.weight"), self.w("norm_out.bias"), dh, dx, _g(self.p("norm_out.weight")), _g(self.p("norm_out.bias")),
-                      True, False)
+                      True, False, dx_bf16=dx16)
         while self.saved:
             rec = self.saved.pop()
             kind = rec[0]
             if kind == "res":
-                dx = self._res_bwd(rec, dx)
+                dx, dx16 = self._res_bwd(rec, dx, dx16)
             elif kind == "attn":
-                dx = self._attn_bwd(rec, dx)
+                dx, dx16 = self._attn_bwd(rec, dx), None
             elif kind == "down":
                 _, name, x16 = rec
-                conv_wgrad(dx, x16, _g(self.p(name + ".weight")), _g(self.p(name + ".bias")), stride=2, pad=0)
-                dx = down_dgrad(dx, self.w(name + ".weight"))
+                conv_wgrad(dx16 if dx16 is not None else dx, x16, _g(self.p(name + ".weight")), _g(self.p(name + ".bias")), stride=2, pad=0)
+                dx, dx16 = down_dgrad(dx, self.w(name + ".weight")), None
             elif kind == "conv_in":
                 cube = rec[1]
                 Bc, R, A, E, cch = cube.shape

@@ -118,6 +118,16 @@ def test_groupnorm_swish_forward_backward_vs_autograd():
         e = (rel_l2(_cf(dx.cpu()) - 1, x.grad), rel_l2(dg.cpu(), g.grad), rel_l2(db.cpu(), b.grad))
         print(f"groupnorm C={Cc} swish={swish}: dx {e[0]:.2e} dgamma {e[1]:.2e} dbeta {e[2]:.2e}")
         assert max(e) < 1e-4
+        # the forms the encoder's backward uses: activations re-created from the saved statistics, dx also (or only) as bf16
+        assert torch.equal(TE.groupnorm_apply(xc, stats, g.detach().cuda(), b.detach().cuda(), swish), y16)
+        dx2, dx16 = torch.ones_like(xc), torch.zeros(xc.shape, device="cuda", dtype=torch.bfloat16)
+        dg2, db2 = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+        TE.groupnorm_bwd(xc, stats, g.detach().cuda(), b.detach().cuda(), _cl(da).cuda(), dx2, dg2, db2, swish, accumulate=True, dx_bf16=dx16)
+        # (the group sums of pass 1 meet in atomics: two launches agree to summation order, the bf16 copy is the rounding of ITS launch's dx)
+        assert rel_l2(dx2.cpu(), dx.cpu()) < 1e-6 and torch.equal(dx16, dx2.bfloat16())
+        only16 = torch.zeros_like(dx16)
+        TE.groupnorm_bwd(xc, stats, g.detach().cuda(), b.detach().cuda(), _cl(da).cuda(), None, dg2, db2, swish, accumulate=False, dx_bf16=only16)
+        assert rel_l2(only16.float().cpu(), (dx - 1).cpu()) < 4e-3
 
 
 def test_encoder_and_tokeniser_forward_backward_vs_oracle_autograd():
