@@ -416,10 +416,14 @@ static int tn_reduce(const float* slab, const float* slab_b, int ranges, int N1,
     return 0;
 }
 
-// row ranges of the generic kernel: a multiple of 8 (one per XCD), ~1024 workgroups, at least 256 rows (4 k-steps) per range
-static void tn_ranges(int M, int N1, int N2, int& rows, int& used, int& launched) {
+// row ranges of the generic kernel: a multiple of 8 (one per XCD), at least 256 rows (4 k-steps) per range.  Atomic form: ~1024 workgroups.
+// Slab form: one range per XCD once there are 32 tiles (measured at 4 096 rows, tools/bench_tn_target.py: 512 x 2048 39.8 -> 29.6 us,
+// 1536 x 512 34.5 -> 28.9 us against the atomic form's count; 4096 x 512 is 8 ranges either way) - every further range is another slab to
+// write and to sum.
+static void tn_ranges(int M, int N1, int N2, int& rows, int& used, int& launched, bool slab) {
     const int t1 = cdiv(N1, 128), t2 = cdiv(N2, 128);
-    int splits = cdiv(1024, t1 * t2);
+    int splits = cdiv(RALD_PROBE_ENV("RALD_TN_TARGET", 1024), t1 * t2);
+    if (slab && RALD_PROBE_ENV("RALD_TN_TARGET", 0) == 0) splits = t1 * t2 >= 32 ? 8 : (int)round_up(cdiv(256, t1 * t2), 8);
     const int max_splits = cdiv(M, 256);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -431,7 +435,7 @@ static void tn_ranges(int M, int N1, int N2, int& rows, int& used, int& launched
 static int tn_launch(GemmTnArgs a, bool conv, hipStream_t st, float* workspace = nullptr) {
     const int t1 = cdiv(a.N1, 128), t2 = cdiv(a.N2, 128);
     int rows, used, splits;
-    tn_ranges(a.M, a.N1, a.N2, rows, used, splits);
+    tn_ranges(a.M, a.N1, a.N2, rows, used, splits, workspace != nullptr && a.N1 > 64);
     RALD_CHECK((int64_t)t1 * t2 * splits < ((int64_t)1 << 31), "gemm_tn: grid too large");
     a.rows_per_split = rows; a.t1 = t1; a.t2 = t2;
     const dim3 grid((unsigned)(t1 * t2 * splits));
@@ -454,7 +458,7 @@ static int tn_launch(GemmTnArgs a, bool conv, hipStream_t st, float* workspace =
 int64_t gemm_tn_workspace_floats(int M, int N1, int N2) {
     if (M < 1 || N1 <= 64 || N2 < 8) return 0;                  // the narrow form keeps its atomics
     int rows, used, launched;
-    tn_ranges(M, N1, N2, rows, used, launched);
+    tn_ranges(M, N1, N2, rows, used, launched, true);
     return (int64_t)used * ((int64_t)N1 * N2 + N1);
 }
 int gemm_tn(const bf16* A, int64_t lda, const bf16* B, int64_t ldb, float* C, int64_t ldc, float* colsum, int M, int N1, int N2, hipStream_t st,
@@ -509,7 +513,7 @@ WgradPlan wgrad_plan(int B, int ID, int IH, int IW, int Cin, int Cout, int strid
         p.splits = (int)round_up(p.used, 8);                     // (ranges past the last step return at once)
     } else {
         int rows;
-        tn_ranges(B * OD * OH * OW, Cout, 27 * Cin, rows, p.used, p.splits);
+        tn_ranges(B * OD * OH * OW, Cout, 27 * Cin, rows, p.used, p.splits, Cout > 64);
     }
     return p;
 }

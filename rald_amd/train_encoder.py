@@ -166,7 +166,6 @@ class EncoderTrainer:
     def _res_fwd(self, x, name, cin, cout):
         h1, st1 = groupnorm(x, self.w(name + ".norm1.weight"), self.w(name + ".norm1.bias"), True)
         t1 = conv3d(h1, pack_conv(self.w(name + ".conv1.weight")), self.w(name + ".conv1.bias"))
-        del h1
         h2, st2 = groupnorm(t1, self.w(name + ".norm2.weight"), self.w(name + ".norm2.bias"), True)
         res = x
         if cin != cout:
@@ -174,19 +173,19 @@ class EncoderTrainer:
             res = op_gemm_nt(x16.view(-1, cin), self.w(name + ".nin_shortcut.weight").view(cout, cin).to(torch.bfloat16),
                              bias=self.w(name + ".nin_shortcut.bias"), epilogue=1).view(*x.shape[:-1], cout)
         out = conv3d(h2, pack_conv(self.w(name + ".conv2.weight")), self.w(name + ".conv2.bias"), resid=res)
-        self.saved.append(("res", name, cin, cout, x, st1, t1, st2))
+        # the normalised activations are kept for the weight gradients (bf16: half the size of x / t1 beside them; 3 GB per iteration at
+        # B = 8 of the 288 GB) instead of being re-created in the backward pass
+        self.saved.append(("res", name, cin, cout, x, st1, t1, st2, h1, h2))
         return out
 
     def _res_bwd(self, rec, dout, dout16=None):
         """dout: fp32 gradient w.r.t. the block's output, dout16 its bf16 copy when the producer already made one.  The convolution
         gradients read bf16: every gradient tensor is rounded ONCE (by the GroupNorm backward that produces it, in the same pass) and
-        that copy feeds both the weight- and the data-gradient convolution; activations are re-created from the saved statistics
-        without a second statistics pass.  Returns (dx fp32, dx bf16)."""
-        _, name, cin, cout, x, st1, t1, st2 = rec
+        that copy feeds both the weight- and the data-gradient convolution.  Returns (dx fp32, dx bf16)."""
+        _, name, cin, cout, x, st1, t1, st2, h1, h2 = rec
         P = lambda n: self.p(name + n)
         if dout16 is None:
             dout16 = TO.cast_bf16(dout)
-        h2 = groupnorm_apply(t1, st2, P(".norm2.weight").data, P(".norm2.bias").data, True)
         conv_wgrad(dout16, h2, _g(P(".conv2.weight")), _g(P(".conv2.bias")))
         del h2
         dh2 = conv_dgrad(dout16, P(".conv2.weight").data)
@@ -194,7 +193,6 @@ class EncoderTrainer:
         groupnorm_bwd(t1, st2, P(".norm2.weight").data, P(".norm2.bias").data, dh2, None, _g(P(".norm2.weight")), _g(P(".norm2.bias")), True, False,
                       dx_bf16=dt1)
         del dh2
-        h1 = groupnorm_apply(x, st1, P(".norm1.weight").data, P(".norm1.bias").data, True)
         conv_wgrad(dt1, h1, _g(P(".conv1.weight")), _g(P(".conv1.bias")))
         del h1
         dh1 = conv_dgrad(dt1, P(".conv1.weight").data)
