@@ -357,10 +357,14 @@ int rald_op_groupnorm_bwd(const float* x, const double* stats, const float* gamm
 int rald_op_groupnorm_apply(const float* x, const double* stats, const float* gamma, const float* beta, void* y_bf16, int32_t B, int32_t S, int32_t C,
                             int32_t swish, void* stream);
 /* rald_op_groupnorm_bwd that also leaves the resulting dx rounded to bf16 in dx_bf16 (what the convolution gradients of the next layer read);
- * dx may be null when only the bf16 form is wanted (not with accumulate) */
-int rald_op_groupnorm_bwd_cast(const float* x, const double* stats, const float* gamma, const float* beta, const float* da, float* dx, void* dx_bf16,
-                               float* dgamma, float* dbeta, double* gsum_scratch, int32_t B, int32_t S, int32_t C, int32_t swish, int32_t accumulate,
-                               void* stream);
+ * dx may be null when only the bf16 form is wanted (not with accumulate); da may hold bf16 (da_is_bf16 = 1) */
+int rald_op_groupnorm_bwd_cast(const float* x, const double* stats, const float* gamma, const float* beta, const void* da, int32_t da_is_bf16, float* dx,
+                               void* dx_bf16, float* dgamma, float* dbeta, double* gsum_scratch, int32_t B, int32_t S, int32_t C, int32_t swish,
+                               int32_t accumulate, void* stream);
+/* rald_op_conv3d with a bf16 result and no residual: the data-gradient convolutions of the training step, whose only reader is the
+ * GroupNorm backward (da_is_bf16 = 1 above) */
+int rald_op_conv3d_bf16(const void* in_bf16, const void* w_packed_bf16, const float* bias, void* out_bf16, int32_t B, int32_t ID, int32_t IH, int32_t IW,
+                        int32_t Cin, int32_t Cout, int32_t stride, int32_t pad, void* stream);
 /* conv_in (Cin = 1 read in place from channel 0 of the cube) and its weight gradient dW [Cout][27] (accumulated) */
 int rald_op_conv_in(const float* cube, int32_t cube_ch, int32_t Cin, const float* W, const float* bias, float* out, int32_t B, int32_t D, int32_t H,
                     int32_t Wd, int32_t Cout, void* stream);

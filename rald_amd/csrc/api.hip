@@ -394,6 +394,11 @@ int rald_op_conv3d(const void* in_bf16, const void* w_packed_bf16, const float* 
                    int32_t IH, int32_t IW, int32_t Cin, int32_t Cout, int32_t stride, int32_t pad, void* stream) {
     return conv3d_igemm((const bf16*)in_bf16, (const bf16*)w_packed_bf16, bias, resid, out, B, ID, IH, IW, Cin, Cout, stride, pad, (hipStream_t)stream);
 }
+int rald_op_conv3d_bf16(const void* in_bf16, const void* w_packed_bf16, const float* bias, void* out_bf16, int32_t B, int32_t ID, int32_t IH, int32_t IW,
+                        int32_t Cin, int32_t Cout, int32_t stride, int32_t pad, void* stream) {
+    return conv3d_igemm((const bf16*)in_bf16, (const bf16*)w_packed_bf16, bias, nullptr, nullptr, B, ID, IH, IW, Cin, Cout, stride, pad, (hipStream_t)stream,
+                        (bf16*)out_bf16);
+}
 int rald_op_groupnorm(const float* x, const float* gamma, const float* beta, void* y_bf16, double* stats, int32_t B, int32_t S, int32_t C,
                       int32_t swish, void* stream) {
     return groupnorm_fwd(x, gamma, beta, (bf16*)y_bf16, stats, B, S, C, swish, (hipStream_t)stream);
@@ -406,10 +411,11 @@ int rald_op_groupnorm_apply(const float* x, const double* stats, const float* ga
                             int32_t swish, void* stream) {
     return groupnorm_apply(x, stats, gamma, beta, (bf16*)y_bf16, B, S, C, swish, (hipStream_t)stream);
 }
-int rald_op_groupnorm_bwd_cast(const float* x, const double* stats, const float* gamma, const float* beta, const float* da, float* dx, void* dx_bf16,
-                               float* dgamma, float* dbeta, double* gsum_scratch, int32_t B, int32_t S, int32_t C, int32_t swish, int32_t accumulate,
-                               void* stream) {
-    return groupnorm_bwd(x, stats, gamma, beta, da, dx, dgamma, dbeta, gsum_scratch, B, S, C, swish, accumulate, (hipStream_t)stream, (bf16*)dx_bf16);
+int rald_op_groupnorm_bwd_cast(const float* x, const double* stats, const float* gamma, const float* beta, const void* da, int32_t da_is_bf16, float* dx,
+                               void* dx_bf16, float* dgamma, float* dbeta, double* gsum_scratch, int32_t B, int32_t S, int32_t C, int32_t swish,
+                               int32_t accumulate, void* stream) {
+    return groupnorm_bwd(x, stats, gamma, beta, (const float*)da, dx, dgamma, dbeta, gsum_scratch, B, S, C, swish, accumulate, (hipStream_t)stream,
+                         (bf16*)dx_bf16, da_is_bf16);
 }
 int rald_op_conv_in(const float* cube, int32_t cube_ch, int32_t Cin, const float* W, const float* bias, float* out, int32_t B, int32_t D, int32_t H,
                     int32_t Wd, int32_t Cout, void* stream) {

@@ -297,7 +297,7 @@ int edm_loss_grad(const float* F, const float* xn, const float* y, const float* 
 
 // ---------------------------------------------------------------- radar.hip / radar_train.hip (encoder, op level)
 int conv3d_igemm(const bf16* in, const bf16* w_packed, const float* bias, const float* resid, float* out, int B, int ID, int IH, int IW,
-                 int Cin, int Cout, int stride, int pad, hipStream_t st);
+                 int Cin, int Cout, int stride, int pad, hipStream_t st, bf16* out_bf16 = nullptr);
 int groupnorm_fwd(const float* x, const float* gamma, const float* beta, bf16* y, double* stats, int B, int S, int C, int swish, hipStream_t st);
 int conv_in_fwd(const float* cube, int cube_ch, int Cin, const float* W, const float* bias, float* out, int B, int D, int H, int Wd, int Cout,
                 hipStream_t st);
@@ -307,7 +307,7 @@ int zero_insert2(const float* dy, bf16* out, int B, int OD, int OH, int OW, int 
 int im2col_t(const bf16* x, bf16* out, int B, int ID, int IH, int IW, int C, int stride, int pad, int64_t m0, int nchunk, hipStream_t st);
 int conv_in_wgrad(const float* cube, int cube_ch, const float* dy, int B, int D, int H, int Wd, int Cout, float* dW, hipStream_t st);
 int groupnorm_bwd(const float* x, const double* stats, const float* gamma, const float* beta, const float* da, float* dx, float* dgamma, float* dbeta,
-                  double* gsum_scratch, int B, int S, int C, int swish, int accumulate, hipStream_t st, bf16* dx_bf16 = nullptr);
+                  double* gsum_scratch, int B, int S, int C, int swish, int accumulate, hipStream_t st, bf16* dx_bf16 = nullptr, int da_is_bf16 = 0);
 int groupnorm_apply(const float* x, const double* stats, const float* gamma, const float* beta, bf16* y, int B, int S, int C, int swish, hipStream_t st);
 int rowdot(const bf16* a, const bf16* b, int64_t M, int C, float* out, hipStream_t st);
 

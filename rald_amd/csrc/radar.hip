@@ -186,6 +186,9 @@ struct ConvArgs {
     // optional split-K (few tiles, long K: the 64- and 512-voxel levels): gridDim.z workgroups share a tile, each takes a contiguous
     // range of k-steps and writes its raw accumulators to split_part[z][M][Cout]; conv_split_reduce_kernel adds them in order
     float* split_part = nullptr;
+    // optional: the result as bf16 INSTEAD of fp32 (training: a data gradient whose only reader is the GroupNorm backward - half the bytes
+    // written here and read twice there); no residual, no split-K
+    bf16* out16 = nullptr;
 };
 
 // Epilogue shared by the two convolution kernels: bias (+ fp32 residual), fp32 store, optional GroupNorm partials of the output.
@@ -214,7 +217,8 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[4][2], const ConvArgs
                 const float4 r = *reinterpret_cast<const float4*>(a.resid + m * a.Cout + n);
                 o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
             }
-            *reinterpret_cast<float4*>(a.out + m * a.Cout + n) = o;
+            if (a.out16) *reinterpret_cast<bf16x4*>(a.out16 + m * a.Cout + n) = pack4(o.x, o.y, o.z, o.w);
+            else *reinterpret_cast<float4*>(a.out + m * a.Cout + n) = o;
             cs[j][0] += o.x; cs[j][1] += o.y; cs[j][2] += o.z; cs[j][3] += o.w;
             cq[j][0] += o.x * o.x; cq[j][1] += o.y * o.y; cq[j][2] += o.z * o.z; cq[j][3] += o.w * o.w;
         }
@@ -1044,12 +1048,13 @@ RadarEncoder::~RadarEncoder() { delete impl; }
 
 // ---- op-level launchers of the kernels above (used by the training path, radar_train.hip / train_encoder.py) ------
 int conv3d_igemm(const bf16* in, const bf16* w_packed, const float* bias, const float* resid, float* out, int B, int ID, int IH, int IW,
-                 int Cin, int Cout, int stride, int pad, hipStream_t st) {
-    RALD_CHECK(in && w_packed && bias && out, "conv3d: null pointer");
+                 int Cin, int Cout, int stride, int pad, hipStream_t st, bf16* out_bf16) {
+    RALD_CHECK(in && w_packed && bias && (out || out_bf16), "conv3d: null pointer");
+    RALD_CHECK(!out_bf16 || (!out && !resid && (uintptr_t)out_bf16 % 8 == 0), "conv3d: the bf16 result replaces the fp32 one and takes no residual");
     RALD_CHECK(B > 0 && ID > 0 && IH > 0 && IW > 0 && (stride == 1 || stride == 2), "conv3d: bad geometry");
     RALD_CHECK(Cin % 64 == 0 && Cout % 4 == 0, "conv3d: Cin must be a multiple of 64 and Cout of 4");
     ConvArgs a;
-    a.in = in; a.w = w_packed; a.bias = bias; a.resid = resid; a.out = out;
+    a.in = in; a.w = w_packed; a.bias = bias; a.resid = resid; a.out = out; a.out16 = out_bf16;
     a.B = B; a.ID = ID; a.IH = IH; a.IW = IW; a.Cin = Cin; a.Cout = Cout; a.stride = stride; a.pad = pad;
     a.OD = ID / stride; a.OH = IH / stride; a.OW = IW / stride;
     launch_conv(a, st);

@@ -214,6 +214,7 @@ struct GnBwdArgs {
     const float* x; const double* stats; const float* gamma; const float* beta; const float* da;
     float* dx; float* dgamma; float* dbeta; double* gsum;
     int S, C, swish, accumulate; float eps;
+    int da16;                                               // da holds bf16 (a data-gradient convolution's bf16 result) instead of fp32
     bf16* dxb;                                              // optional: the (accumulated) dx rounded to bf16 - what the convolution gradients read; dx may then be null
 };
 __device__ __forceinline__ float gn_dy(float yv, float da, int swish) {
@@ -247,7 +248,10 @@ __global__ __launch_bounds__(256) void gn_bwd_pass_kernel(GnBwdArgs a, int pass,
     float pg[4] = {0, 0, 0, 0}, pb[4] = {0, 0, 0, 0}, g1[4] = {0, 0, 0, 0}, g2[4] = {0, 0, 0, 0};
     for (int v = v0 + threadIdx.x / quads; v < v1; v += vstep) {
         const int64_t idx = ((int64_t)b * a.S + v) * quads + q;
-        const float4 t = reinterpret_cast<const float4*>(a.x)[idx], d = reinterpret_cast<const float4*>(a.da)[idx];
+        const float4 t = reinterpret_cast<const float4*>(a.x)[idx];
+        float4 d;
+        if (a.da16) { const bf16x4 h = reinterpret_cast<const bf16x4*>(a.da)[idx]; d = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]); }
+        else d = reinterpret_cast<const float4*>(a.da)[idx];
         const float xv[4] = {t.x, t.y, t.z, t.w}, dv[4] = {d.x, d.y, d.z, d.w};
         float o[4];
 #pragma unroll
@@ -286,14 +290,14 @@ __global__ __launch_bounds__(256) void gn_bwd_pass_kernel(GnBwdArgs a, int pass,
     }
 }
 int groupnorm_bwd(const float* x, const double* stats, const float* gamma, const float* beta, const float* da, float* dx, float* dgamma, float* dbeta,
-                  double* gsum_scratch, int B, int S, int C, int swish, int accumulate, hipStream_t st, bf16* dx_bf16) {
+                  double* gsum_scratch, int B, int S, int C, int swish, int accumulate, hipStream_t st, bf16* dx_bf16, int da_is_bf16) {
     RALD_CHECK(x && stats && gamma && beta && da && (dx || dx_bf16) && dgamma && dbeta && gsum_scratch, "groupnorm_bwd: null pointer");
     RALD_CHECK(dx || !accumulate, "groupnorm_bwd: accumulating needs the fp32 dx");
     RALD_CHECK((uintptr_t)dx_bf16 % 8 == 0, "groupnorm_bwd: the bf16 copy must be 8-byte aligned");
     RALD_CHECK(B > 0 && S > 0 && C % 64 == 0 && C <= 256 && 256 % (C / 4) == 0, "groupnorm_bwd: channel count must be 64, 128 or 256");
     GnBwdArgs a;
     a.x = x; a.stats = stats; a.gamma = gamma; a.beta = beta; a.da = da; a.dx = dx; a.dgamma = dgamma; a.dbeta = dbeta; a.gsum = gsum_scratch;
-    a.S = S; a.C = C; a.swish = swish; a.accumulate = accumulate; a.eps = 1e-6f; a.dxb = dx_bf16;
+    a.S = S; a.C = C; a.swish = swish; a.accumulate = accumulate; a.eps = 1e-6f; a.dxb = dx_bf16; a.da16 = da_is_bf16;
     RALD_HIP(hipMemsetAsync(gsum_scratch, 0, (size_t)B * 32 * 2 * 8, st));
     const int vpb = 1024;
     hipLaunchKernelGGL(gn_bwd_pass_kernel, dim3(cdiv(S, vpb), B), dim3(256), 0, st, a, 1, vpb);

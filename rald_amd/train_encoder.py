@@ -43,10 +43,16 @@ def pack_conv(W: torch.Tensor, dgrad: bool = False, pad_to: Optional[int] = None
     return out
 
 
-def conv3d(x16: torch.Tensor, wp: torch.Tensor, bias: torch.Tensor, resid: Optional[torch.Tensor] = None, stride: int = 1, pad: int = 1):
-    """x16 bf16 [B, D, H, W, Cin], wp packed [Cout][27][Cin] -> f32 [B, D/s, H/s, W/s, Cout] (+ resid)."""
+def conv3d(x16: torch.Tensor, wp: torch.Tensor, bias: torch.Tensor, resid: Optional[torch.Tensor] = None, stride: int = 1, pad: int = 1,
+           out_bf16: bool = False):
+    """x16 bf16 [B, D, H, W, Cin], wp packed [Cout][27][Cin] -> f32 [B, D/s, H/s, W/s, Cout] (+ resid), or the same as bf16 (no resid)."""
     B, D, H, W, Cin = x16.shape
     Cout = wp.shape[0]
+    if out_bf16:
+        assert resid is None
+        out = torch.empty(B, D // stride, H // stride, W // stride, Cout, device=x16.device, dtype=torch.bfloat16)
+        check(lib().rald_op_conv3d_bf16(_p(x16), _p(wp), _p(bias), _p(out), B, D, H, W, Cin, Cout, stride, pad, _st()))
+        return out
     out = torch.empty(B, D // stride, H // stride, W // stride, Cout, device=x16.device, dtype=torch.float32)
     check(lib().rald_op_conv3d(_p(x16), _p(wp), _p(bias), _p(resid), _p(out), B, D, H, W, Cin, Cout, stride, pad, _st()))
     return out
@@ -77,19 +83,20 @@ def groupnorm_bwd(x, stats, gamma, beta, da, dx, dgamma, dbeta, swish: bool, acc
     S = x.numel() // (B * Cc)
     scratch = torch.empty(B, 32, 2, device=x.device, dtype=torch.float64)
     if dx_bf16 is None:
+        assert da.dtype == torch.float32
         check(lib().rald_op_groupnorm_bwd(_p(x), _p(stats), _p(gamma), _p(beta), _p(da), _p(dx), _p(dgamma), _p(dbeta), _p(scratch), B, S, Cc,
                                           int(swish), int(accumulate), _st()))
     else:
-        check(lib().rald_op_groupnorm_bwd_cast(_p(x), _p(stats), _p(gamma), _p(beta), _p(da), _p(dx), _p(dx_bf16), _p(dgamma), _p(dbeta), _p(scratch),
-                                               B, S, Cc, int(swish), int(accumulate), _st()))
+        check(lib().rald_op_groupnorm_bwd_cast(_p(x), _p(stats), _p(gamma), _p(beta), _p(da), int(da.dtype == torch.bfloat16), _p(dx), _p(dx_bf16),
+                                               _p(dgamma), _p(dbeta), _p(scratch), B, S, Cc, int(swish), int(accumulate), _st()))
 
 
 def _zero_bias(n, dev):
     return torch.zeros(n, device=dev, dtype=torch.float32)
 
 
-def conv_dgrad(dy: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
-    """Gradient w.r.t. the input of a k3 s1 p1 conv: dy f32 [B, D, H, W, Cout], W the f32 parameter -> f32 [B, D, H, W, Cin]."""
+def conv_dgrad(dy: torch.Tensor, W: torch.Tensor, out_bf16: bool = False) -> torch.Tensor:
+    """Gradient w.r.t. the input of a k3 s1 p1 conv: dy f32 or bf16 [B, D, H, W, Cout], W the f32 parameter -> f32 (or bf16) [B, D, H, W, Cin]."""
     Cout, Cin = W.shape[0], W.shape[1]
     cpad = -(-Cout // 64) * 64
     B = dy.shape[0]
@@ -99,7 +106,7 @@ def conv_dgrad(dy: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
     else:
         dy16 = torch.empty(*dy.shape[:-1], cpad, device=dy.device, dtype=torch.bfloat16)
         check(lib().rald_op_pad_channels(_p(dy.float() if dy.dtype != torch.float32 else dy), _p(dy16), M, Cout, cpad, _st()))
-    return conv3d(dy16, pack_conv(W, dgrad=True, pad_to=cpad), _zero_bias(Cin, dy.device), None, 1, 1)
+    return conv3d(dy16, pack_conv(W, dgrad=True, pad_to=cpad), _zero_bias(Cin, dy.device), None, 1, 1, out_bf16=out_bf16)
 
 
 def down_dgrad(dy: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
@@ -188,14 +195,14 @@ class EncoderTrainer:
             dout16 = TO.cast_bf16(dout)
         conv_wgrad(dout16, h2, _g(P(".conv2.weight")), _g(P(".conv2.bias")))
         del h2
-        dh2 = conv_dgrad(dout16, P(".conv2.weight").data)
+        dh2 = conv_dgrad(dout16, P(".conv2.weight").data, out_bf16=True)     # read only by the GroupNorm backward
         dt1 = torch.empty(t1.shape, device=t1.device, dtype=torch.bfloat16)                 # consumed by the two convolution gradients only
         groupnorm_bwd(t1, st2, P(".norm2.weight").data, P(".norm2.bias").data, dh2, None, _g(P(".norm2.weight")), _g(P(".norm2.bias")), True, False,
                       dx_bf16=dt1)
         del dh2
         conv_wgrad(dt1, h1, _g(P(".conv1.weight")), _g(P(".conv1.bias")))
         del h1
-        dh1 = conv_dgrad(dt1, P(".conv1.weight").data)
+        dh1 = conv_dgrad(dt1, P(".conv1.weight").data, out_bf16=True)
         if cin == cout:
             dx = dout
         else:
@@ -325,7 +332,7 @@ class EncoderTrainer:
         dz5 = dz.view(*x.shape[:-1], dz.shape[-1])
         h = groupnorm_apply(x, st, self.w("norm_out.weight"), self.w("norm_out.bias"), True)
         conv_wgrad(dz5, h, _g(self.p("conv_out.weight")), _g(self.p("conv_out.bias")))
-        dh = conv_dgrad(dz5, self.w("conv_out.weight"))
+        dh = conv_dgrad(dz5, self.w("conv_out.weight"), out_bf16=True)
         dx, dx16 = torch.empty_like(x), torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
         groupnorm_bwd(x, st, self.w("norm_out.weight"), self.w("norm_out.bias"), dh, dx, _g(self.p("norm_out.weight")), _g(self.p("norm_out.bias")),
                       True, False, dx_bf16=dx16)

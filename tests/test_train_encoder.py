@@ -35,6 +35,10 @@ def test_conv3d_forward_dgrad_wgrad_vs_autograd():
         dx = TE.conv_dgrad(_cl(dy).cuda(), Wt.detach().cuda())
         print("conv dgrad rel_l2", rel_l2(_cf(dx.cpu()), x.grad))
         assert rel_l2(_cf(dx.cpu()), x.grad) < 1e-2
+        # bf16 dy in (Cout a multiple of 64: read as it lies) and the bf16 result the GroupNorm backward reads: the fp32 result rounded
+        if Cout % 64 == 0:
+            dx16 = TE.conv_dgrad(_cl(dy).bfloat16().cuda(), Wt.detach().cuda(), out_bf16=True)
+            assert dx16.dtype == torch.bfloat16 and torch.equal(dx16, dx.bfloat16())
         dW, db = torch.zeros_like(Wt, device="cuda"), torch.zeros(Cout, device="cuda")
         TE.conv_wgrad(_cl(dy).cuda(), x16, dW, db)
         print("conv wgrad rel_l2", rel_l2(dW.cpu(), Wt.grad), rel_l2(db.cpu(), dy.sum((0, 2, 3, 4))))
@@ -128,6 +132,13 @@ def test_groupnorm_swish_forward_backward_vs_autograd():
         only16 = torch.zeros_like(dx16)
         TE.groupnorm_bwd(xc, stats, g.detach().cuda(), b.detach().cuda(), _cl(da).cuda(), None, dg2, db2, swish, accumulate=False, dx_bf16=only16)
         assert rel_l2(only16.float().cpu(), (dx - 1).cpu()) < 4e-3
+        # da handed over as bf16 (a data-gradient convolution's bf16 result): the fp32 math on the rounded values
+        da16 = _cl(da).bfloat16().cuda()
+        ref = torch.zeros_like(xc)
+        TE.groupnorm_bwd(xc, stats, g.detach().cuda(), b.detach().cuda(), da16.float(), ref, dg2, db2, swish, accumulate=False)
+        got, got16 = torch.zeros_like(xc), torch.zeros_like(dx16)
+        TE.groupnorm_bwd(xc, stats, g.detach().cuda(), b.detach().cuda(), da16, got, dg2, db2, swish, accumulate=False, dx_bf16=got16)
+        assert rel_l2(got.cpu(), ref.cpu()) < 1e-6 and torch.equal(got16, got.bfloat16())
 
 
 def test_encoder_and_tokeniser_forward_backward_vs_oracle_autograd():
