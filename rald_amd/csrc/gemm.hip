@@ -301,12 +301,26 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_glds_kernel(GemmArgs a) 
         unsigned char* base = smem + buf * STAGE_BYTES;
         int ks = kt + koff;
         ks = ks >= nk_ ? ks - nk_ : ks;
+        // probe builds (timing only, wrong results): bits 4096 / 8192 drop the B / A pieces of every stage after the first two - is a k-step
+        // paced by the BYTES of its stage or by the latency of a stage, whatever its size?
+        // (the probe library's main loop is ~2 x slower than the shipped one - its run-time switches sit between the MFMAs - so the same question
+        // is asked of the shipped loop with compile-time variants: tools/build_variant.sh ska -DRALD_SKIP_A, skb -DRALD_SKIP_B, skab with both)
+#if defined(RALD_SKIP_A)
+        const bool skip_a = kt >= 2;
+#else
+        const bool skip_a = RALD_ABLATED(a.ablate, 8192) && kt >= 2;
+#endif
+#if defined(RALD_SKIP_B)
+        const bool skip_b = kt >= 2;
+#else
+        const bool skip_b = RALD_ABLATED(a.ablate, 4096) && kt >= 2;
+#endif
 #pragma unroll
         for (int p = 0; p < CA; ++p)
-            __builtin_amdgcn_global_load_lds((glb_void*)(gA[p] + ks * BK), (lds_void*)(base + (wave + WAVES * p) * 1024), 16, 0, 0);
+            if (!skip_a) __builtin_amdgcn_global_load_lds((glb_void*)(gA[p] + ks * BK), (lds_void*)(base + (wave + WAVES * p) * 1024), 16, 0, 0);
 #pragma unroll
         for (int p = 0; p < CB; ++p)
-            __builtin_amdgcn_global_load_lds((glb_void*)(gB[p] + ks * BK), (lds_void*)(base + BM * 128 + (wave + WAVES * p) * 1024), 16, 0, 0);
+            if (!skip_b) __builtin_amdgcn_global_load_lds((glb_void*)(gB[p] + ks * BK), (lds_void*)(base + BM * 128 + (wave + WAVES * p) * 1024), 16, 0, 0);
     };
 
     f32x4 acc[MT][NT];
@@ -340,6 +354,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_glds_kernel(GemmArgs a) 
             for (int j = 0; j < NT; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     };
+    // Measured and removed (round 3, tools/ab_libs_gemm.py on compile-time variants of this loop): (a) dropping the A pieces, the B pieces or all
+    // DMA after the prologue (-DRALD_SKIP_A / -DRALD_SKIP_B, wrong results, timing only) takes FF1 at B = 64 on random operands 167 -> 161 / 161
+    // / 151 us and its K = 2048 form 442 -> 406 / 400 / 367 us: with NO global traffic a k-step still takes 1.25 us against 1.54 with it and
+    // 1.09 of pure MFMA time at the ~1.9 GHz the chip holds in this loop - the loop is matrix-pipe-bound at the power-limited clock, the whole DMA
+    // path costs 10-17 % (about what issuing 8-10 LDS-DMA instructions per wave and k-step costs), which is why no prefetch / ring / persistent
+    // variant ever gained; (b) the same loop on v_mfma_f32_32x32x16_bf16 (half the MFMA instructions and operand-register reads per FLOP, same
+    // LDS traffic): 5-8 % SLOWER (173 -> 184 us, 446 -> 480 us).
     if constexpr (NSTAGE == 2) {
         // Software-pipelined main loop, rotated so that an iteration starts right AFTER a tile hand-over (barrier): nothing is
         // pending on the LDS counter at the loop head, so the compiler's waits inside the iteration are exact counts (round 2: the

@@ -357,6 +357,10 @@ class EdmTrainer:
             base = self.opt.flat_g.data_ptr()
             los = [((p.grad.data_ptr() - base) // 4, p.numel()) for k, p in self.model.named_parameters() if k.startswith("model.")]
             self._mrange = (min(l for l, _ in los), max(l + n for l, n in los))
+            # the range must hold the transformer's gradients and nothing else: were another parameter's gradient interleaved, its bucket
+            # would travel before that gradient is final
+            if sum(n for _, n in los) != self._mrange[1] - self._mrange[0]:
+                raise RuntimeError("EdmTrainer: the gradients of model.* are not one contiguous range of the flat gradient buffer")
         return self._mrange
 
     def forward_backward(self, y, cube, rnd_normal, noise):
