@@ -350,7 +350,9 @@ int rald_op_conv_pack_weights(const float* W, void* out_bf16, int32_t Cout, int3
  * {sum, sumsq} are kept for the backward, the rest is scratch for the per-block partials of the deterministic (atomic-free) reduction */
 int rald_op_groupnorm(const float* x, const float* gamma, const float* beta, void* y_bf16, double* stats, int32_t B, int32_t S, int32_t C,
                       int32_t swish, void* stream);
-/* its backward: da = gradient w.r.t. the (activated) output; dx written or accumulated; dgamma/dbeta accumulated; gsum_scratch [B][32][2] doubles */
+/* its backward: da = gradient w.r.t. the (activated) output; dx written or accumulated; dgamma/dbeta accumulated; gsum_scratch: 8-byte aligned,
+ * rald_op_groupnorm_bwd_scratch_bytes(B, S, C) bytes (group sums + the per-workgroup partial sums of the atomic-free, bit-reproducible reduction) */
+int64_t rald_op_groupnorm_bwd_scratch_bytes(int32_t B, int32_t S, int32_t C);
 int rald_op_groupnorm_bwd(const float* x, const double* stats, const float* gamma, const float* beta, const float* da, float* dx, float* dgamma,
                           float* dbeta, double* gsum_scratch, int32_t B, int32_t S, int32_t C, int32_t swish, int32_t accumulate, void* stream);
 /* rald_op_groupnorm's normalisation alone, from the [B][32][2] statistics a forward call left (the training backward re-creates activations) */

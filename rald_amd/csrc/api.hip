@@ -407,6 +407,7 @@ int rald_op_groupnorm_bwd(const float* x, const double* stats, const float* gamm
                           float* dbeta, double* gsum_scratch, int32_t B, int32_t S, int32_t C, int32_t swish, int32_t accumulate, void* stream) {
     return groupnorm_bwd(x, stats, gamma, beta, da, dx, dgamma, dbeta, gsum_scratch, B, S, C, swish, accumulate, (hipStream_t)stream);
 }
+int64_t rald_op_groupnorm_bwd_scratch_bytes(int32_t B, int32_t S, int32_t C) { return groupnorm_bwd_scratch_bytes(B, S, C); }
 int rald_op_groupnorm_apply(const float* x, const double* stats, const float* gamma, const float* beta, void* y_bf16, int32_t B, int32_t S, int32_t C,
                             int32_t swish, void* stream) {
     return groupnorm_apply(x, stats, gamma, beta, (bf16*)y_bf16, B, S, C, swish, (hipStream_t)stream);

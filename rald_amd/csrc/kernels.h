@@ -308,6 +308,7 @@ int im2col_t(const bf16* x, bf16* out, int B, int ID, int IH, int IW, int C, int
 int conv_in_wgrad(const float* cube, int cube_ch, const float* dy, int B, int D, int H, int Wd, int Cout, float* dW, hipStream_t st);
 int groupnorm_bwd(const float* x, const double* stats, const float* gamma, const float* beta, const float* da, float* dx, float* dgamma, float* dbeta,
                   double* gsum_scratch, int B, int S, int C, int swish, int accumulate, hipStream_t st, bf16* dx_bf16 = nullptr, int da_is_bf16 = 0);
+int64_t groupnorm_bwd_scratch_bytes(int B, int S, int C);   // what gsum_scratch of groupnorm_bwd must hold
 int groupnorm_apply(const float* x, const double* stats, const float* gamma, const float* beta, bf16* y, int B, int S, int C, int swish, hipStream_t st);
 int rowdot(const bf16* a, const bf16* b, int64_t M, int C, float* out, hipStream_t st);
 

@@ -208,12 +208,16 @@ int conv_in_wgrad(const float* cube, int cube_ch, const float* dy, int B, int D,
 
 // ---- GroupNorm (+ swish) backward -------------------------------------------------------------------------------
 // forward: y = xhat * gamma + beta (xhat over the group's S*cpg elements), a = swish(y) or y.  Given da:
-//   pass 1: dgamma[c] += sum dy*xhat, dbeta[c] += sum dy, gsum[b][g] += {sum dy*gamma, sum dy*gamma*xhat}
-//   pass 2: dx (+)= rstd * (dy*gamma - gsum0/n - xhat * gsum1/n)
+//   pass 1: per workgroup (1 024 voxels of one sample) the partial sums  sum dy*xhat, sum dy  per channel and  sum dy*gamma, sum dy*gamma*xhat
+//           per group, reduced in a FIXED order through LDS and stored as that workgroup's row of the scratch table (no atomics);
+//   finish: per sample, the rows added in order -> gsum[b][g] (double) and the sample's channel sums;
+//   pass 2: dx (+)= rstd * (dy*gamma - gsum0/n - xhat * gsum1/n); its first workgroup adds the samples' channel sums, in order, into dgamma / dbeta.
+// Bit-reproducible run to run (round 2's form met in fp32 / fp64 atomics: 2 048 workgroups on the same 128 + 64 addresses at full resolution).
 struct GnBwdArgs {
     const float* x; const double* stats; const float* gamma; const float* beta; const float* da;
     float* dx; float* dgamma; float* dbeta; double* gsum;
     int S, C, swish, accumulate; float eps;
+    float* part; float* csum; int nblk;                     // scratch: part[b][blk][2C + 64] (pass 1), csum[b][2C] (finish); nblk = workgroups per sample
     int da16;                                               // da holds bf16 (a data-gradient convolution's bf16 result) instead of fp32
     bf16* dxb;                                              // optional: the (accumulated) dx rounded to bf16 - what the convolution gradients read; dx may then be null
 };
@@ -224,8 +228,7 @@ __device__ __forceinline__ float gn_dy(float yv, float da, int swish) {
 }
 __global__ __launch_bounds__(256) void gn_bwd_pass_kernel(GnBwdArgs a, int pass, int vox_per_block) {
     __shared__ float smean[32], srstd[32], sm1[32], sm2[32];
-    __shared__ float cacc[2][256];                          // per-channel partials (C <= 256)
-    __shared__ float gacc[2][32];
+    __shared__ float red[4][256][4];                        // pass 1: every thread's four partial sums of its four channels
     const int b = blockIdx.y, C = a.C, cpg = C / 32, quads = C / 4;
     if (threadIdx.x < 32) {
         const double n = (double)a.S * cpg;
@@ -237,9 +240,14 @@ __global__ __launch_bounds__(256) void gn_bwd_pass_kernel(GnBwdArgs a, int pass,
             sm1[threadIdx.x] = (float)(a.gsum[((int64_t)b * 32 + threadIdx.x) * 2] / n);
             sm2[threadIdx.x] = (float)(a.gsum[((int64_t)b * 32 + threadIdx.x) * 2 + 1] / n);
         }
-        gacc[0][threadIdx.x] = 0.f; gacc[1][threadIdx.x] = 0.f;
     }
-    cacc[0][threadIdx.x] = 0.f; cacc[1][threadIdx.x] = 0.f;
+    if (pass == 2 && blockIdx.x == 0 && b == 0) {           // the samples' channel sums, in order, into the parameter gradients (once per launch)
+        for (int t = threadIdx.x; t < 2 * C; t += 256) {
+            float sacc = 0.f;
+            for (int bb_ = 0; bb_ < (int)gridDim.y; ++bb_) sacc += a.csum[(int64_t)bb_ * 2 * C + t];
+            if (t < C) a.dgamma[t] += sacc; else a.dbeta[t - C] += sacc;
+        }
+    }
     __syncthreads();
     const int q = threadIdx.x % quads, vstep = 256 / quads;
     const int v0 = blockIdx.x * vox_per_block, v1 = min(a.S, v0 + vox_per_block);
@@ -275,19 +283,44 @@ __global__ __launch_bounds__(256) void gn_bwd_pass_kernel(GnBwdArgs a, int pass,
     }
     if (pass == 2) return;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        atomicAdd(&cacc[0][4 * q + j], pg[j]);
-        atomicAdd(&cacc[1][4 * q + j], pb[j]);
-        const int g = (4 * q + j) / cpg;
-        atomicAdd(&gacc[0][g], g1[j]);
-        atomicAdd(&gacc[1][g], g2[j]);
-    }
+    for (int j = 0; j < 4; ++j) { red[0][threadIdx.x][j] = pg[j]; red[1][threadIdx.x][j] = pb[j]; red[2][threadIdx.x][j] = g1[j]; red[3][threadIdx.x][j] = g2[j]; }
     __syncthreads();
-    if (threadIdx.x < C) { atomicAdd(a.dgamma + threadIdx.x, cacc[0][threadIdx.x]); atomicAdd(a.dbeta + threadIdx.x, cacc[1][threadIdx.x]); }
-    if (threadIdx.x < 32) {
-        atomicAdd(&a.gsum[((int64_t)b * 32 + threadIdx.x) * 2], (double)gacc[0][threadIdx.x]);
-        atomicAdd(&a.gsum[((int64_t)b * 32 + threadIdx.x) * 2 + 1], (double)gacc[1][threadIdx.x]);
+    // fixed order: the vstep row lanes of a channel, then (group sums) the channels of the group
+    float* prow = a.part + ((int64_t)b * a.nblk + blockIdx.x) * (2 * C + 64);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int L = 0; L < vstep; ++L) { s0 += red[0][L * quads + (c >> 2)][c & 3]; s1 += red[1][L * quads + (c >> 2)][c & 3]; }
+        prow[c] = s0; prow[C + c] = s1;
     }
+    if (threadIdx.x >= 192 && threadIdx.x < 224) {          // (a wave of its own next to the channel sums above)
+        const int g = threadIdx.x - 192;
+        float s0 = 0.f, s1 = 0.f;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c)
+            for (int L = 0; L < vstep; ++L) { s0 += red[2][L * quads + (c >> 2)][c & 3]; s1 += red[3][L * quads + (c >> 2)][c & 3]; }
+        prow[2 * C + g] = s0; prow[2 * C + 32 + g] = s1;
+    }
+}
+// per sample: the workgroups' rows added in order
+__global__ __launch_bounds__(256) void gn_bwd_finish_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ csum, double* __restrict__ gsum) {
+    const int b = blockIdx.x, W = 2 * C + 64;
+    for (int t = threadIdx.x; t < W; t += 256) {
+        const float* p = part + (int64_t)b * nblk * W + t;
+        if (t < 2 * C) {
+            float sacc = 0.f;
+            for (int k = 0; k < nblk; ++k) sacc += p[(int64_t)k * W];
+            csum[(int64_t)b * 2 * C + t] = sacc;
+        } else {
+            double sacc = 0.0;
+            for (int k = 0; k < nblk; ++k) sacc += (double)p[(int64_t)k * W];
+            const int g = (t - 2 * C) & 31, which = (t - 2 * C) >> 5;
+            gsum[((int64_t)b * 32 + g) * 2 + which] = sacc;
+        }
+    }
+}
+int64_t groupnorm_bwd_scratch_bytes(int B, int S, int C) {
+    if (B < 1 || S < 1 || C < 64) return 0;
+    const int64_t nblk = (S + 1023) / 1024;
+    return (int64_t)B * 64 * 8 + ((int64_t)B * nblk * (2 * C + 64) + (int64_t)B * 2 * C) * 4;
 }
 int groupnorm_bwd(const float* x, const double* stats, const float* gamma, const float* beta, const float* da, float* dx, float* dgamma, float* dbeta,
                   double* gsum_scratch, int B, int S, int C, int swish, int accumulate, hipStream_t st, bf16* dx_bf16, int da_is_bf16) {
@@ -298,10 +331,13 @@ int groupnorm_bwd(const float* x, const double* stats, const float* gamma, const
     GnBwdArgs a;
     a.x = x; a.stats = stats; a.gamma = gamma; a.beta = beta; a.da = da; a.dx = dx; a.dgamma = dgamma; a.dbeta = dbeta; a.gsum = gsum_scratch;
     a.S = S; a.C = C; a.swish = swish; a.accumulate = accumulate; a.eps = 1e-6f; a.dxb = dx_bf16; a.da16 = da_is_bf16;
-    RALD_HIP(hipMemsetAsync(gsum_scratch, 0, (size_t)B * 32 * 2 * 8, st));
     const int vpb = 1024;
-    hipLaunchKernelGGL(gn_bwd_pass_kernel, dim3(cdiv(S, vpb), B), dim3(256), 0, st, a, 1, vpb);
-    hipLaunchKernelGGL(gn_bwd_pass_kernel, dim3(cdiv(S, vpb), B), dim3(256), 0, st, a, 2, vpb);
+    a.nblk = cdiv(S, vpb);
+    a.part = reinterpret_cast<float*>(gsum_scratch + (size_t)B * 64);                   // caller contract: groupnorm_bwd_scratch_bytes(B, S, C)
+    a.csum = a.part + (size_t)B * a.nblk * (2 * C + 64);
+    hipLaunchKernelGGL(gn_bwd_pass_kernel, dim3(a.nblk, B), dim3(256), 0, st, a, 1, vpb);
+    hipLaunchKernelGGL(gn_bwd_finish_kernel, dim3(B), dim3(256), 0, st, a.part, a.nblk, C, a.csum, gsum_scratch);
+    hipLaunchKernelGGL(gn_bwd_pass_kernel, dim3(a.nblk, B), dim3(256), 0, st, a, 2, vpb);
     RALD_HIP(hipGetLastError());
     return 0;
 }

@@ -81,7 +81,7 @@ def groupnorm_bwd(x, stats, gamma, beta, da, dx, dgamma, dbeta, swish: bool, acc
     """dx (fp32, may be None when only ``dx_bf16`` is wanted) written or accumulated; dx_bf16 (optional) = the resulting dx rounded to bf16."""
     B, Cc = x.shape[0], x.shape[-1]
     S = x.numel() // (B * Cc)
-    scratch = torch.empty(B, 32, 2, device=x.device, dtype=torch.float64)
+    scratch = torch.empty((lib().rald_op_groupnorm_bwd_scratch_bytes(B, S, Cc) + 7) // 8, device=x.device, dtype=torch.float64)
     if dx_bf16 is None:
         assert da.dtype == torch.float32
         check(lib().rald_op_groupnorm_bwd(_p(x), _p(stats), _p(gamma), _p(beta), _p(da), _p(dx), _p(dgamma), _p(dbeta), _p(scratch), B, S, Cc,
