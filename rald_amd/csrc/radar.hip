@@ -195,7 +195,7 @@ struct ConvArgs {
 // acc[i][j][e] <-> voxel m0 + wm*64 + i*16 + fr, channel n0 + wn*32 + j*16 + 4*fq + e.  Must be reached by the whole workgroup
 // after the K-loop's last barrier (it reuses the staging LDS when a.gn_part is set).
 __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[4][2], const ConvArgs& a, int64_t M, int64_t m0, int n0, int wm, int wn, int fr,
-                                              int fq, int tid, unsigned char* smem) {
+                                              int fq, int tid, unsigned char* smem, int64_t tile128 = -1) {
     constexpr int BM = 128, BN = 64, MT = 4, NT = 2;
     float cs[NT][4], cq[NT][4];                 // per-lane channel sums over this lane's MT voxels (GroupNorm partials)
 #pragma unroll
@@ -242,7 +242,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[4][2], const ConvArgs
             double su = 0.0, sq = 0.0;
             for (int w = 0; w < 2; ++w)
                 for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { su += (double)sc[w * 64 + c].x; sq += (double)sc[w * 64 + c].y; }
-            double* o = a.gn_part + ((int64_t)blockIdx.y * 32 + n0 / cpg + tid) * 2;
+            double* o = a.gn_part + ((tile128 >= 0 ? tile128 : (int64_t)blockIdx.y) * 32 + n0 / cpg + tid) * 2;
             o[0] = su; o[1] = sq;
         }
     }
@@ -529,6 +529,161 @@ __global__ __launch_bounds__(256) void conv3d_line_kernel(ConvArgs a, int lw) {
     conv_epilogue(acc, a, M, m0, n0, wm, wn, fr, fq, tid, smem);
 }
 
+// Plane-staged form for the 64-channel levels: a workgroup of 8 waves takes 256 output voxels = L = 256 / OW whole w-lines of ONE (b, d) plane
+// and stages everything those voxels ever read - the three d-planes x (L + 2) h-lines x (OW + 2) columns, <= 1 024 rows of 128 B = 128 KiB -
+// ONCE; the 27 taps then only index into that image, and the only traffic of the main loop is the weights of one (kd, kh) pair at a time
+// (3 taps, 24 KiB, from L2).  conv3d_line_kernel re-stages its lines for each of the nine (kd, kh) pairs (360 KB per 256 voxels instead of
+// 130 KB) and, worse, WAITS for them: with one or two k-steps of prefetch in registers a step lasts as long as a trip to memory - 3.6 us per
+// pair for 0.7 us of MFMA work, 18 GB/s per CU, whatever the inner loop looks like (a 3-taps-per-barrier form of that kernel with
+// software-pipelined fragment reads measured exactly the same 515 us per full-resolution convolution of 4 samples).  Here a tile pays the trip
+// once.  Measured (radar-condition encode at B = 8, eight full-resolution launches): 7.72 -> 7.06 ms, 515 -> ~455 us per launch; with the
+// staging loads redirected to one address (compile-time variant) 7.05 ms, without the epilogue 6.06 ms - what is left of a 28 us tile is ~7 us of
+// prologue (16 rows of address arithmetic, loads and LDS stores per thread, one exposed trip to memory), ~12 us of main loop (6.6 us of MFMA work:
+// two barriers and one exposed fragment-read latency per pair, one workgroup per CU) and 8.5 us of epilogue (residual read, GroupNorm partial
+// sums, fp32 stores) that nothing overlaps.  Host contract: stride 1, pad 1, Cin = 64, Cout % 64 == 0, OW in {16, 32}, OH % L == 0 (a tile never leaves its plane), M % 256 == 0.
+// LDS (dynamic): 128 KiB of lines + 24 KiB of weights; the epilogue's scratch reuses the weights' 24 KiB.
+__global__ __launch_bounds__(512) void conv3d_plane_kernel(ConvArgs a, int lw) {
+    constexpr int BN = 64, MT = 4, NT = 2, RE_MAX = 1024, PAX = RE_MAX / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+    bf16x8* sA = reinterpret_cast<bf16x8*>(smem3);                        // [RE rows][8 chunks], row e = ((kd * (L + 2)) + l) * (OW + 2) + we
+    bf16x8* sB = reinterpret_cast<bf16x8*>(smem3 + RE_MAX * 128);         // [3 taps][64 couts][8 chunks]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t M = (int64_t)a.B * a.OD * a.OH * a.OW;
+    const int64_t m0 = (int64_t)blockIdx.y * 256;
+    const int n0 = blockIdx.x * BN;
+    const int srow = tid >> 3, schunk = tid & 7;
+    const int OW = 1 << lw, EW = OW + 2, L = 256 >> lw, LH = L + 2, PL = LH * EW, RE = 3 * PL;
+    const int64_t ln0 = m0 >> lw;
+    const int oh0 = (int)(ln0 % a.OH);
+    const int64_t pl = ln0 / a.OH;
+    const int od = (int)(pl % a.OD), b = (int)(pl / a.OD);
+    int rw = n0 + srow;
+    rw = rw < a.Cout ? rw : a.Cout - 1;
+    const bf16* gW = a.w + (int64_t)rw * 27 * 64 + schunk * 8;               // (Cin = 64: tap t of output channel rw at element t * 64)
+    // the weights run THREE pairs ahead of their use in a register ring (12 VGPRs per pair): with one pair of prefetch every pair waited for its
+    // weights - all 256 CUs ask the L2 for the same 24 KiB at the same moment, ~3 us a trip - and a tile took 30 us for 6.6 us of MFMA work
+    bf16x8 rB[3][3];
+    auto loadW = [&](int pair, auto SLOT) {
+        constexpr int sl = decltype(SLOT)::value;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) rB[sl][kw] = *reinterpret_cast<const bf16x8*>(gW + (pair * 3 + kw) * 64);
+    };
+    auto storeW = [&](auto SLOT) {
+        constexpr int sl = decltype(SLOT)::value;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) sB[(kw * BN + srow) * 8 + (schunk ^ (srow & 7))] = rB[sl][kw];
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    {   // the tile's whole input image, once: unconditional loads from clamped addresses, zeros selected at the LDS store
+        bf16x8 rA[PAX];
+        unsigned rvalid = 0;
+#pragma unroll
+        for (int p = 0; p < PAX; ++p) {
+            const int e = srow + 64 * p;
+            const int kd = e / PL, rem = e - kd * PL;
+            const int l = rem / EW, we = rem - l * EW;
+            const int id = od + kd - 1, ih = oh0 - 1 + l, iw = we - 1;
+            const bool ok = e < RE && (unsigned)id < (unsigned)a.ID && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW;
+            const int64_t off = ok ? ((((int64_t)b * a.ID + id) * a.IH + ih) * a.IW + iw) * 64 + schunk * 8 : (int64_t)schunk * 8;
+            rA[p] = *reinterpret_cast<const bf16x8*>(a.in + off);
+            rvalid |= ok ? (1u << p) : 0u;
+        }
+        loadW(0, S0{});
+        loadW(1, S1{});
+        loadW(2, S2{});
+        bf16x8 zero;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) zero[j] = (bf16)0.f;
+#pragma unroll
+        for (int p = 0; p < PAX; ++p) {
+            const int e = srow + 64 * p;
+            if (e < RE) sA[e * 8 + (schunk ^ (e & 7))] = (rvalid >> p) & 1 ? rA[p] : zero;
+        }
+        storeW(S0{});
+        loadW(3, S0{});
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+    int ebase[MT];                                                           // staged row of this lane's voxel for tap (0, 0, 0)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int r = wm * 64 + i * 16 + fr;
+        ebase[i] = (r >> lw) * EW + (r & (OW - 1));
+    }
+    // fragments of one tap (both 32-deep halves), double-buffered: tap kw + 1 is read under the MFMAs of tap kw
+    bf16x8 fa[2][2][MT], fb[2][2][NT];
+    auto rd = [&](int poff, int kw, auto BUF) {
+        constexpr int bb = decltype(BUF)::value;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int chunk = kk * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int e = ebase[i] + poff + kw;
+                fa[bb][kk][i] = sA[e * 8 + (chunk ^ (e & 7))];
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int r = wn * (BN / 2) + j * 16 + fr;
+                fb[bb][kk][j] = sB[(kw * BN + r) * 8 + (chunk ^ (r & 7))];
+            }
+        }
+    };
+    auto mm = [&](auto BUF) {
+        constexpr int bb = decltype(BUF)::value;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[bb][kk][j], fa[bb][kk][i], acc[i][j], 0, 0, 0);
+    };
+    using F0 = std::integral_constant<int, 0>;
+    using F1 = std::integral_constant<int, 1>;
+    __syncthreads();
+    auto step = [&](auto PAIR) {
+        constexpr int pair = decltype(PAIR)::value;
+        constexpr int kd = pair / 3, kh = pair - 3 * kd;
+        const int poff = (kd * LH + kh) * EW;
+        rd(poff, 0, F0{});
+        __builtin_amdgcn_sched_barrier(0);
+        rd(poff, 1, F1{});
+        mm(F0{});
+#pragma unroll
+        for (int g = 0; g < 12; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(poff, 2, F0{});
+        mm(F1{});
+#pragma unroll
+        for (int g = 0; g < 12; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(F0{});
+        __syncthreads();                                                      // every wave has read this pair's weights
+        if constexpr (pair + 1 < 9) {
+            using SL = std::integral_constant<int, (pair + 1) % 3>;
+            storeW(SL{});                                                     // pair + 1, loaded three pairs ago
+            if constexpr (pair + 4 < 9) loadW(pair + 4, SL{});
+            __syncthreads();
+        }
+    };
+    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+    // the epilogue is the 128-voxel one, once per half of the tile (waves 0-3 / 4-7); its scratch lies in the weights' area
+    conv_epilogue(acc, a, M, m0 + (wm >> 1) * 128, n0, wm & 1, wn, fr, fq, tid & 255, smem3 + RE_MAX * 128 + (wm >> 1) * 2048,
+                  2 * (int64_t)blockIdx.y + (wm >> 1));
+}
+
 // engine choice for one convolution (RALD_CONV_LINE=0 keeps the per-tap gather kernel everywhere: A/B switch)
 static void launch_conv(const ConvArgs& a, hipStream_t st) {
     static const bool line = RALD_PROBE_ENV("RALD_CONV_LINE", 1) != 0;
@@ -537,6 +692,14 @@ static void launch_conv(const ConvArgs& a, hipStream_t st) {
     const bool pow2 = a.OW == 8 || a.OW == 16 || a.OW == 32;
     if (line && a.stride == 1 && a.pad == 1 && pow2 && M % 128 == 0 && a.Cin % 64 == 0 && a.OD == a.ID && a.OH == a.IH && a.OW == a.IW) {
         const int lw = a.OW == 8 ? 3 : a.OW == 16 ? 4 : 5;
+        static const bool plane = RALD_PROBE_ENV("RALD_CONV_PLANE", 1) != 0;
+        const int Lp = 256 >> lw;
+        if (plane && a.Cin == 64 && a.Cout % 64 == 0 && lw >= 4 && a.OH % Lp == 0 && M % 256 == 0 && M / 256 >= 256 && 3 * (Lp + 2) * (a.OW + 2) <= 1024) {
+            constexpr int LDSP = 1024 * 128 + 3 * 64 * 128;                  // the tile's input image staged once + one (kd, kh) pair of weights
+            static bool attr_set = false;
+            if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv3d_plane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDSP); attr_set = true; }
+            hipLaunchKernelGGL(conv3d_plane_kernel, dim3(cdiv(a.Cout, 64), (unsigned)(M / 256)), dim3(512), LDSP, st, a, lw);
+        } else
         hipLaunchKernelGGL(conv3d_line_kernel, grid, dim3(256), 0, st, a, lw);
     } else {
         hipLaunchKernelGGL(conv3d_igemm_kernel, grid, dim3(256), 0, st, a);
