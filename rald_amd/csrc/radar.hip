@@ -195,7 +195,8 @@ struct ConvArgs {
 // acc[i][j][e] <-> voxel m0 + wm*64 + i*16 + fr, channel n0 + wn*32 + j*16 + 4*fq + e.  Must be reached by the whole workgroup
 // after the K-loop's last barrier (it reuses the staging LDS when a.gn_part is set).
 __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[4][2], const ConvArgs& a, int64_t M, int64_t m0, int n0, int wm, int wn, int fr,
-                                              int fq, int tid, unsigned char* smem, int64_t tile128 = -1) {
+                                              int fq, int tid, unsigned char* smem, int64_t tile128 = -1, const float4* pre_bias = nullptr,
+                                              const float4* pre_resid = nullptr) {   // pre_*: this lane's bias [NT] / residual [MT][NT] values, loaded earlier
     constexpr int BM = 128, BN = 64, MT = 4, NT = 2;
     float cs[NT][4], cq[NT][4];                 // per-lane channel sums over this lane's MT voxels (GroupNorm partials)
 #pragma unroll
@@ -210,11 +211,11 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[4][2], const ConvArgs
         for (int j = 0; j < NT; ++j) {
             const int n = n0 + wn * (BN / 2) + j * 16 + 4 * fq;
             if (n >= a.Cout) continue;
-            const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+            const float4 b = pre_bias ? pre_bias[j] : *reinterpret_cast<const float4*>(a.bias + n);
             f32x4 v = acc[i][j];
             float4 o = make_float4(v[0] + b.x, v[1] + b.y, v[2] + b.z, v[3] + b.w);
             if (a.resid) {
-                const float4 r = *reinterpret_cast<const float4*>(a.resid + m * a.Cout + n);
+                const float4 r = pre_resid ? pre_resid[i * NT + j] : *reinterpret_cast<const float4*>(a.resid + m * a.Cout + n);
                 o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
             }
             if (a.out16) *reinterpret_cast<bf16x4*>(a.out16 + m * a.Cout + n) = pack4(o.x, o.y, o.z, o.w);
@@ -678,10 +679,21 @@ __global__ __launch_bounds__(512) void conv3d_plane_kernel(ConvArgs a, int lw) {
     };
     step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
     step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+    // what the epilogue adds - bias and fp32 residual of this lane's outputs - is fetched under the last three pairs (one workgroup per CU:
+    // nothing else would hide that trip to memory; M % 256 == 0 and Cout % 64 == 0, so every index exists)
+    float4 pb[NT], pr[MT * NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) pb[j] = *reinterpret_cast<const float4*>(a.bias + n0 + wn * (BN / 2) + j * 16 + 4 * fq);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            pr[i * NT + j] = a.resid ? *reinterpret_cast<const float4*>(a.resid + (m0 + wm * 64 + i * 16 + fr) * a.Cout + n0 + wn * (BN / 2) + j * 16 + 4 * fq)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
     step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
     // the epilogue is the 128-voxel one, once per half of the tile (waves 0-3 / 4-7); its scratch lies in the weights' area
     conv_epilogue(acc, a, M, m0 + (wm >> 1) * 128, n0, wm & 1, wn, fr, fq, tid & 255, smem3 + RE_MAX * 128 + (wm >> 1) * 2048,
-                  2 * (int64_t)blockIdx.y + (wm >> 1));
+                  2 * (int64_t)blockIdx.y + (wm >> 1), pb, pr);
 }
 
 // engine choice for one convolution (RALD_CONV_LINE=0 keeps the per-tap gather kernel everywhere: A/B switch)
