@@ -696,6 +696,184 @@ __global__ __launch_bounds__(512) void conv3d_plane_kernel(ConvArgs a, int lw) {
                   2 * (int64_t)blockIdx.y + (wm >> 1), pb, pr);
 }
 
+// The plane-staged form made persistent along d: a workgroup walks `ds` consecutive d-planes of one (b, 256-voxel h-block) column with a rolling window of
+// three input planes in LDS (plane id lives in slot id mod 3).  Per output tile it stages ONE new plane instead of three - loaded into registers at the start
+// of the tile, stored over the plane that leaves the window as soon as the kd = 0 pairs have read it - the weights' register ring runs on across tiles (pair (p + 4) mod 9 is
+// fetched under pair p, whatever tile that belongs to), and the next tile's first fragment reads follow this tile's output stores directly: the prologue
+// of conv3d_plane_kernel (address arithmetic, one exposed trip to memory, 16 LDS stores per thread) is paid once per `ds` tiles.
+// grid.y = columns x segments: column = (b, oh0 / L), segment = ds planes.  Host contract: conv3d_plane_kernel's, and OD % ds == 0.
+__global__ __launch_bounds__(512) void conv3d_pplane_kernel(ConvArgs a, int lw, int ds) {
+    constexpr int BN = 64, MT = 4, NT = 2, RE_MAX = 1024, PPX = 6;                 // a plane image is <= 340 rows: 6 staging rows per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+    bf16x8* sA = reinterpret_cast<bf16x8*>(smem3);                        // [3 slots][PL rows][8 chunks]; swizzle by the absolute row index
+    bf16x8* sB = reinterpret_cast<bf16x8*>(smem3 + RE_MAX * 128);         // [3 taps][64 couts][8 chunks]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t M = (int64_t)a.B * a.OD * a.OH * a.OW;
+    const int n0 = blockIdx.x * BN;
+    const int srow = tid >> 3, schunk = tid & 7;
+    const int OW = 1 << lw, EW = OW + 2, L = 256 >> lw, LH = L + 2, PL = LH * EW;
+    const int nseg = a.OD / ds, nhb = a.OH / L;
+    const int seg = blockIdx.y % nseg, col = blockIdx.y / nseg;
+    const int hb = col % nhb, b = col / nhb;
+    const int oh0 = hb * L, d_lo = seg * ds;
+    // this thread's staging rows of a plane image: row e = l * EW + we <-> input (ih = oh0 - 1 + l, iw = we - 1); the same for every plane
+    int rowoff[PPX];                                                         // element offset inside a plane, or -1
+#pragma unroll
+    for (int p = 0; p < PPX; ++p) {
+        const int e = srow + 64 * p;
+        const int l = e / EW, we = e - l * EW;
+        const int ih = oh0 - 1 + l, iw = we - 1;
+        rowoff[p] = (e < PL && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW) ? (ih * a.IW + iw) * 64 + schunk * 8 : -1;
+    }
+    const int64_t plane_elems = (int64_t)a.IH * a.IW * 64;
+    const bf16* inb = a.in + (int64_t)b * a.ID * plane_elems;
+    bf16x8 zero;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zero[j] = (bf16)0.f;
+    auto loadP = [&](int id, bf16x8 (&r)[PPX]) {                              // plane id (may lie outside the volume: zeros at the store)
+        const bool inside = (unsigned)id < (unsigned)a.ID;
+        const bf16* pb_ = inb + (int64_t)(inside ? id : 0) * plane_elems;
+#pragma unroll
+        for (int p = 0; p < PPX; ++p) r[p] = *reinterpret_cast<const bf16x8*>(pb_ + (rowoff[p] >= 0 ? rowoff[p] : schunk * 8));
+    };
+    auto storeP = [&](int id, const bf16x8 (&r)[PPX]) {
+        const bool inside = (unsigned)id < (unsigned)a.ID;
+        const int slot = (id + 3) % 3;
+#pragma unroll
+        for (int p = 0; p < PPX; ++p) {
+            const int e = srow + 64 * p;
+            if (e < PL) { const int ea = slot * PL + e; sA[ea * 8 + (schunk ^ (ea & 7))] = (inside && rowoff[p] >= 0) ? r[p] : zero; }
+        }
+    };
+    int rw = n0 + srow;
+    rw = rw < a.Cout ? rw : a.Cout - 1;
+    const bf16* gW = a.w + (int64_t)rw * 27 * 64 + schunk * 8;
+    bf16x8 rB[3][3];
+    auto loadW = [&](int pair, auto SLOT) {
+        constexpr int sl = decltype(SLOT)::value;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) rB[sl][kw] = *reinterpret_cast<const bf16x8*>(gW + (pair * 3 + kw) * 64);
+    };
+    auto storeW = [&](auto SLOT) {
+        constexpr int sl = decltype(SLOT)::value;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) sB[(kw * BN + srow) * 8 + (schunk ^ (srow & 7))] = rB[sl][kw];
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    bf16x8 rP[PPX];
+    {   // the first window: planes d_lo - 1, d_lo, d_lo + 1
+        bf16x8 r0[PPX], r1[PPX];
+        loadP(d_lo - 1, r0); loadP(d_lo, r1); loadP(d_lo + 1, rP);
+        loadW(0, S0{}); loadW(1, S1{}); loadW(2, S2{});
+        storeP(d_lo - 1, r0); storeP(d_lo, r1); storeP(d_lo + 1, rP);
+        storeW(S0{});
+        loadW(3, S0{});
+    }
+    const int fr = lane & 15, fq = lane >> 4;
+    int ebase[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int r = wm * 64 + i * 16 + fr;
+        ebase[i] = (r >> lw) * EW + (r & (OW - 1));
+    }
+    float4 pb[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) pb[j] = *reinterpret_cast<const float4*>(a.bias + n0 + wn * (BN / 2) + j * 16 + 4 * fq);
+    f32x4 acc[MT][NT];
+    bf16x8 fa[2][2][MT], fb[2][2][NT];
+    auto rd = [&](int poff, int kw, auto BUF) {
+        constexpr int bb = decltype(BUF)::value;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int chunk = kk * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int e = ebase[i] + poff + kw;
+                fa[bb][kk][i] = sA[e * 8 + (chunk ^ (e & 7))];
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int r = wn * (BN / 2) + j * 16 + fr;
+                fb[bb][kk][j] = sB[(kw * BN + r) * 8 + (chunk ^ (r & 7))];
+            }
+        }
+    };
+    auto mm = [&](auto BUF) {
+        constexpr int bb = decltype(BUF)::value;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[bb][kk][j], fa[bb][kk][i], acc[i][j], 0, 0, 0);
+    };
+    using F0 = std::integral_constant<int, 0>;
+    using F1 = std::integral_constant<int, 1>;
+    __syncthreads();
+    for (int d = d_lo; d < d_lo + ds; ++d) {
+        const bool more = d + 1 < d_lo + ds;
+        if (more) loadP(d + 2, rP);                                          // the plane the NEXT tile adds to the window: a whole tile ahead
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int64_t m0 = (((int64_t)b * a.OD + d) * a.OH + oh0) * OW;
+        const int sl0 = (d + 2) % 3;                                          // slot of plane d - 1; d -> (sl0 + 1) % 3, d + 1 -> (sl0 + 2) % 3
+        float4 pr[MT * NT];
+        auto step = [&](auto PAIR) {
+            constexpr int pair = decltype(PAIR)::value;
+            constexpr int kd = pair / 3, kh = pair - 3 * kd;
+            int slot = sl0 + kd;
+            slot = slot >= 3 ? slot - 3 : slot;
+            const int poff = slot * PL + kh * EW;
+            rd(poff, 0, F0{});
+            __builtin_amdgcn_sched_barrier(0);
+            rd(poff, 1, F1{});
+            mm(F0{});
+#pragma unroll
+            for (int g = 0; g < 12; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            rd(poff, 2, F0{});
+            mm(F1{});
+#pragma unroll
+            for (int g = 0; g < 12; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(F0{});
+            __syncthreads();                                                  // every wave has read this pair's weights
+            if constexpr (pair < 8) {
+                using SL = std::integral_constant<int, (pair + 1) % 3>;
+                storeW(SL{});                                                 // pair + 1, loaded three pairs ago
+                loadW((pair + 4) % 9, SL{});                                  // (wraps into the next tile: the weights do not depend on the tile)
+                if constexpr (pair == 2) { if (more) storeP(d + 2, rP); }     // over plane d - 1, whose last readers were pairs 0-2 (frees rP's registers)
+                __syncthreads();
+            }
+        };
+        step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                pr[i * NT + j] = a.resid ? *reinterpret_cast<const float4*>(a.resid + (m0 + wm * 64 + i * 16 + fr) * a.Cout + n0 + wn * (BN / 2) + j * 16 + 4 * fq)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+        // (after pair 8's barrier nobody reads the weights' area: the epilogue's scratch lies there)
+        conv_epilogue(acc, a, M, m0 + (wm >> 1) * 128, n0, wm & 1, wn, fr, fq, tid & 255, smem3 + RE_MAX * 128 + (wm >> 1) * 2048, m0 / 128 + (wm >> 1), pb, pr);
+        if (more) {
+            __syncthreads();                                                  // the epilogue's scratch has been read
+            storeW(S0{});                                                     // pair 0 of the next tile (fetched under pair 5)
+            loadW(3, S0{});
+            __syncthreads();
+        }
+    }
+}
+
 // engine choice for one convolution (RALD_CONV_LINE=0 keeps the per-tap gather kernel everywhere: A/B switch)
 static void launch_conv(const ConvArgs& a, hipStream_t st) {
     static const bool line = RALD_PROBE_ENV("RALD_CONV_LINE", 1) != 0;
@@ -705,7 +883,15 @@ static void launch_conv(const ConvArgs& a, hipStream_t st) {
     if (line && a.stride == 1 && a.pad == 1 && pow2 && M % 128 == 0 && a.Cin % 64 == 0 && a.OD == a.ID && a.OH == a.IH && a.OW == a.IW) {
         const int lw = a.OW == 8 ? 3 : a.OW == 16 ? 4 : 5;
         static const bool plane = RALD_PROBE_ENV("RALD_CONV_PLANE", 1) != 0;
+        static const int pds = RALD_PROBE_ENV("RALD_CONV_PPLANE_DS", 8);      // planes per persistent workgroup (0 = the one-tile kernel)
         const int Lp = 256 >> lw;
+        if (plane && pds > 0 && a.Cin == 64 && a.Cout % 64 == 0 && lw >= 4 && a.OH % Lp == 0 && a.OD % pds == 0 && 3 * (Lp + 2) * (a.OW + 2) <= 1024 &&
+            (int64_t)a.B * (a.OH / Lp) * (a.OD / pds) >= 256) {
+            constexpr int LDSP = 1024 * 128 + 3 * 64 * 128;
+            static bool attr_set = false;
+            if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv3d_pplane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDSP); attr_set = true; }
+            hipLaunchKernelGGL(conv3d_pplane_kernel, dim3(cdiv(a.Cout, 64), (unsigned)(a.B * (a.OH / Lp) * (a.OD / pds))), dim3(512), LDSP, st, a, lw, pds);
+        } else
         if (plane && a.Cin == 64 && a.Cout % 64 == 0 && lw >= 4 && a.OH % Lp == 0 && M % 256 == 0 && M / 256 >= 256 && 3 * (Lp + 2) * (a.OW + 2) <= 1024) {
             constexpr int LDSP = 1024 * 128 + 3 * 64 * 128;                  // the tile's input image staged once + one (kd, kh) pair of weights
             static bool attr_set = false;
