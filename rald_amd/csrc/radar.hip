@@ -232,9 +232,17 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[4][2], const ConvArgs
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+                // the 16 voxel lanes of one fq share a DPP row: four row-local adds (quad swaps, half-mirror, mirror) leave the row's total in every
+                // lane at VALU rate (the ds_bpermute butterfly this replaces was 2.3 us of a 24 us tile: 128 LDS-crossbar ops and their waits)
                 float s1 = cs[j][e], s2 = cq[j][e];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                s1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0xB1, 0xf, 0xf, true));
+                s2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2), 0xB1, 0xf, 0xf, true));
+                s1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0x4E, 0xf, 0xf, true));
+                s2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2), 0x4E, 0xf, 0xf, true));
+                s1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0x141, 0xf, 0xf, true));
+                s2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2), 0x141, 0xf, 0xf, true));
+                s1 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0x140, 0xf, 0xf, true));
+                s2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2), 0x140, 0xf, 0xf, true));
                 if (fr == 0) sc[wm * 64 + wn * 32 + j * 16 + 4 * fq + e] = make_float2(s1, s2);
             }
         __syncthreads();
