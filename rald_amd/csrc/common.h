@@ -53,15 +53,31 @@ inline int probe_env(const char* name, int dflt) { const char* e = getenv(name);
 #endif
 
 // ---- device helpers --------------------------------------------------------------------
+// Wave-wide reductions on DPP (data-parallel primitives: a VALU operand read through a fixed lane permutation) instead of __shfl_xor, which
+// hipcc lowers to six dependent ds_bpermute_b32 - LDS-crossbar round trips of ~60-100 clocks each - per reduction: every LayerNorm-type kernel
+// here is a chain of two or three such reductions per row.  Four row-local steps (quad swaps, half-mirror, mirror) leave each 16-lane row's result
+// in all of its lanes, row_bcast15 / row_bcast31 carry it across the four rows into lane 63, and a readlane hands it to every lane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_read(float keep, float v) {   // lanes of rows outside ROW_MASK (and lanes without a source) receive `keep`
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_read<0xB1, 0xf>(0.f, v);       // quad_perm [1,0,3,2]
+    v += dpp_read<0x4E, 0xf>(0.f, v);       // quad_perm [2,3,0,1]
+    v += dpp_read<0x141, 0xf>(0.f, v);      // row_half_mirror
+    v += dpp_read<0x140, 0xf>(0.f, v);      // row_mirror: every lane now holds its row's sum
+    v += dpp_read<0x142, 0xa>(0.f, v);      // row_bcast15 into rows 1 and 3
+    v += dpp_read<0x143, 0xc>(0.f, v);      // row_bcast31 into rows 2 and 3: lane 63 holds the wave's sum
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_read<0xB1, 0xf>(v, v));
+    v = fmaxf(v, dpp_read<0x4E, 0xf>(v, v));
+    v = fmaxf(v, dpp_read<0x141, 0xf>(v, v));
+    v = fmaxf(v, dpp_read<0x140, 0xf>(v, v));
+    v = fmaxf(v, dpp_read<0x142, 0xa>(v, v));
+    v = fmaxf(v, dpp_read<0x143, 0xc>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 // erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, branch-free: 1 rcp + 1 exp + 6 FMA) - libm's
 // erff is a two-branch polynomial that diverges per lane and costs ~3x as many VALU slots in the
