@@ -225,3 +225,26 @@ def test_module_forward_checks_batch_sizes_before_touching_the_gpu():
         m(torch.zeros(3, 512, 32), torch.tensor([0.1]), cond=torch.zeros(2, 64, 512))
     with pytest.raises(RuntimeError, match="channels"):
         m(torch.zeros(2, 512, 16), torch.tensor([0.1]), cond=torch.zeros(2, 64, 512))
+
+
+def test_training_workspace_queries_are_host_side_and_consistent():
+    """The workspace / scratch sizes of the atomic-free gradient kernels are plain host arithmetic (no GPU needed): they grow with the number of
+    row / voxel ranges, cover at least one range of the full gradient, are 0 where a shape keeps the atomic form, and refuse nonsense."""
+    from rald_amd._lib import lib
+    L = lib()
+    # Linear weight gradient dW [N1, N2] over M rows: (ranges) x (N1*N2 + N1) floats
+    b = L.rald_op_gemm_tn_workspace_bytes(4096, 4096, 512)
+    assert b >= 4 * (4096 * 512 + 4096) and b % (4 * (4096 * 512 + 4096)) == 0
+    assert L.rald_op_gemm_tn_workspace_bytes(4096, 64, 512) == 0             # narrow outputs keep their atomics
+    assert L.rald_op_gemm_tn_workspace_bytes(0, 512, 512) == 0
+    # Conv3d weight gradient at the radar encoder's levels (B = 8): per range Cout*27*Cin + Cout floats
+    for (D, H, W, Cin, Cout) in ((128, 64, 32, 64, 64), (32, 16, 8, 128, 128), (8, 4, 2, 256, 256)):
+        b = L.rald_op_conv3d_wgrad_workspace_bytes(8, D, H, W, Cin, Cout, 1, 1)
+        per = 4 * (Cout * 27 * Cin + Cout)
+        assert b >= per and b % per == 0, (D, H, W, Cin, Cout, b)
+    assert L.rald_op_conv3d_wgrad_workspace_bytes(8, 128, 64, 32, 64, 64, 3, 1) == 0      # unsupported stride
+    # GroupNorm backward scratch: group sums + one row of partial sums per 1 024 voxels and sample + per-sample channel sums
+    B, S, C = 8, 128 * 64 * 32, 64
+    nblk = (S + 1023) // 1024
+    assert L.rald_op_groupnorm_bwd_scratch_bytes(B, S, C) == B * 64 * 8 + (B * nblk * (2 * C + 64) + B * 2 * C) * 4
+    assert L.rald_op_groupnorm_bwd_scratch_bytes(0, S, C) == 0
