@@ -46,6 +46,32 @@ def test_conv3d_forward_dgrad_wgrad_vs_autograd():
         assert rel_l2(dW.cpu(), Wt.grad) < 1e-2 and rel_l2(db.cpu(), dy.sum((0, 2, 3, 4))) < 5e-3
 
 
+@pytest.mark.parametrize("B,D,H,W", [(2, 32, 64, 32), (4, 64, 64, 32), (4, 32, 32, 16)])
+def test_plane_staged_convolution_equals_the_line_staged_one_on_a_crop(B, D, H, W):
+    """The 64-channel convolutions of large volumes run on the plane-staged kernels (csrc/radar.hip: conv3d_plane_kernel, and its persistent
+    form conv3d_pplane_kernel from 256 columns x segments up - the second shape); small volumes stay on conv3d_line_kernel.  A convolution is
+    local: the result on a d-slab of the big volume must equal the result on that slab cropped out with a one-plane halo - computed by the
+    other kernel.  fp32 accumulation of the same 1 728 products per output in both: 1e-6; with the residual and as bf16 output too."""
+    from rald_amd import train_encoder as TE
+    Cc = 64
+    x16 = synth.normal([B, D, H, W, Cc], 640).bfloat16().cuda()
+    Wt = (synth.normal([Cc, Cc, 3, 3, 3], 641) / (Cc * 27) ** 0.5).cuda()
+    bias = (synth.normal([Cc], 642) * 0.1).cuda()
+    resid = synth.normal([B, D, H, W, Cc], 643).cuda()
+    wp = TE.pack_conv(Wt)
+    big = TE.conv3d(x16, wp, bias)
+    big_r = TE.conv3d(x16, wp, bias, resid=resid)
+    big_16 = TE.conv3d(x16, wp, bias, out_bf16=True)
+    assert torch.equal(big_16, big.bfloat16())
+    for b, d0 in ((0, 0), (B - 1, D - 8), (B // 2, D // 2 - 4)):
+        lo, hi = max(d0 - 1, 0), min(d0 + 9, D)                      # the slab [d0, d0 + 8) with its halo planes where they exist
+        crop = TE.conv3d(x16[b:b + 1, lo:hi].contiguous(), wp, bias)
+        crop_r = TE.conv3d(x16[b:b + 1, lo:hi].contiguous(), wp, bias, resid=resid[b:b + 1, lo:hi].contiguous())
+        sl = slice(d0 - lo, d0 - lo + 8)
+        assert rel_l2(big[b, d0:d0 + 8].cpu(), crop[0, sl].cpu()) < 1e-6, (b, d0)
+        assert rel_l2(big_r[b, d0:d0 + 8].cpu(), crop_r[0, sl].cpu()) < 1e-6, (b, d0)
+
+
 def test_weight_gradients_through_the_workspace_are_bit_reproducible_and_match_the_atomic_form():
     """conv3d / Linear weight gradients with the row ranges meeting in a workspace (summed in order by a second launch) instead of
     fp32 atomics: two runs give identical bits, the result accumulates INTO the destination, and it equals the atomic form to fp32
