@@ -220,7 +220,11 @@ def main():
     barrier(world)
     h.profile_begin()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        # the dominant kernel (FF1) is bracketed by HIP events on every launch of the timed region; the three residual + LayerNorm GEMMs on its
+        # first three NFEs only: an event pair costs ~2.5 us of stream time and 96 pairs per NFE took 0.5 ms (2.5 %) off the rate being measured
+        if i == 3:
+            h.profile_set_kinds(0x1)
         h.denoise(x, cache, 0)
     barrier(world)
     elapsed = time.perf_counter() - t0
@@ -230,8 +234,16 @@ def main():
 
     total_units = world * B * args.steps
     value = total_units / elapsed
-    # dominant kernel: the FF1 GEGLU GEMM [B*512, 512] x [512, 4096] (40% of an NFE's FLOPs)
-    ff1_flops = 2.0 * (B * 512) * 4096 * 512
+    # which of the two bit-identical schedules of an NFE this box runs (rald_amd/_handles.py: timed once per handle and batch size between 128
+    # and 255 samples): the whole batch, or two half-batches on two streams - then the timed launches are the first half's, Bt samples each
+    tuned = h._two_stream_tuned.get(B)
+    split = bool(tuned and tuned[0])
+    Bt = ((B // 2 + 32) // 64) * 64 if split else B
+    schedule = ("two half-batches (%d + %d samples) on two streams" % (Bt, B - Bt)) if split else "whole batch on one stream"
+    if tuned:
+        schedule += "; this box: whole %.2f ms, split %.2f ms per NFE" % (tuned[1], tuned[2])
+    # dominant kernel: the FF1 GEGLU GEMM [Bt*512, 512] x [512, 4096] (40% of an NFE's FLOPs)
+    ff1_flops = 2.0 * (Bt * 512) * 4096 * 512
     avg_s = (ff1_ms / max(ff1_launches, 1)) * 1e-3
     achieved = ff1_flops / avg_s / 1e12 if avg_s > 0 else 0.0
     traffic, traffic_commit, tj = None, None, {}
@@ -239,11 +251,11 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            traffic = tj.get(f"ff1_geglu_gemm_B{B}")
+            traffic = tj.get(f"ff1_geglu_gemm_B{Bt}")
             traffic_commit = tj.get("_source_sha")
         except Exception:
             traffic = None
-    M = B * 512
+    M = Bt * 512
     # the three fused residual + LayerNorm GEMMs (x += A.W^T + b; h = AdaLN(x)): largest time share of an NFE.  Algorithmic HBM bytes per
     # launch: A bf16 [M,K] + x fp32 read and written [M,512] + h bf16 [M,512] (+ W, once); FLOPs 2.M.512.K
     def ln_roofline(kind, K, name):
@@ -252,14 +264,14 @@ def main():
             return None
         t = ms / n * 1e-3
         flops = 2.0 * M * 512 * K
-        byt = M * K * 2 + M * 512 * (4 + 4 + 2) + 512 * K * 2 * (B if kind == 2 else 1)      # (kind 2: one folded weight matrix per sample)
+        byt = M * K * 2 + M * 512 * (4 + 4 + 2) + 512 * K * 2 * (Bt if kind == 2 else 1)     # (kind 2: one folded weight matrix per sample)
         hbm, mf = byt / t / 1e9, flops / t / 1e12
         bound = "hbm" if hbm / PEAK_HBM_GBS > mf / PEAK_BF16_TFLOPS else "mfma"
         return {"kernel": name, "bound": bound, "achieved": hbm if bound == "hbm" else mf, "peak": PEAK_HBM_GBS if bound == "hbm" else PEAK_BF16_TFLOPS,
                 "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": (hbm / PEAK_HBM_GBS) if bound == "hbm" else (mf / PEAK_BF16_TFLOPS),
                 "tflops": mf, "hbm_gbs": hbm, "avg_launch_us": t * 1e6, "launches_timed": n,
                 "algorithmic_bytes_per_launch": byt, "algorithmic_flop_per_launch": flops,
-                "traffic": (tj.get("in_situ_bytes_per_launch", {}) or {}).get(f"{name.split(' ')[0]}_B{B}")}
+                "traffic": (tj.get("in_situ_bytes_per_launch", {}) or {}).get(f"{name.split(' ')[0]}_B{Bt}")}
     roofline_ln = [r for r in (ln_roofline(1, 512, "gemm_resid_ln_K512_attn1 (to_out + residual + AdaLN)"),
                                ln_roofline(2, 512, "gemm_resid_ln_K512_attn2 (folded cross-attention output + residual + AdaLN, per-sample weights)"),
                                ln_roofline(3, 2048, "gemm_resid_ln_K2048_ff2 (ff.net.2 + residual + AdaLN)")) if r]
@@ -271,6 +283,7 @@ def main():
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "configs[2]: kl_d512_m512_l32_d24_edm denoiser NFE, 512x32 latents, 64x512 radar condition tokens (cached)",
                    "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"batch-sharded x{world}, no data-path collective",
+                   "nfe_schedule": schedule, "samples_per_timed_launch": Bt,
                    "weights": "seeded random (rald_amd.weights, seed 0)", "env": env, "commit": git_commit(), "source_sha": source_fingerprint()},
         "whole_path_tflops": value * GFLOP_PER_NFE / 1e3,
         "heun_steps_per_s": value * 18.0 / 35.0, "samples_per_s_18step": value / 35.0,

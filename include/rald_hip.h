@@ -128,6 +128,10 @@ int rald_dit_profile_end(rald_dit* h, double* total_ms, int32_t* launches);
  * + AdaLN (K = 512), [3] ff.net.2 + residual + AdaLN (K = 2048).  total_ms4 / launches4 point at 4 elements each.  Batches that
  * take another engine for a kind (small M) report 0 launches there. */
 int rald_dit_profile_end_kinds(rald_dit* h, double* total_ms4, int32_t* launches4);
+/* Between begin and end: which kinds are bracketed from now on (bit k = kind k; begin resets it to all four).  An event pair costs ~2.5 us of
+ * stream time, 96 pairs per NFE at 24 blocks: a measurement that also reports the whole-job rate brackets the three residual + LayerNorm
+ * kinds on a few NFEs only and the dominant kernel on all of them. */
+int rald_dit_profile_set_kinds(rald_dit* h, uint32_t kind_mask);
 
 /* ------------------------------------------------------------------------------------------
  * Set-latent autoencoder: KLAutoEncoder, query_type='mix' or 'learnable'  (model/models_ae.py:284-432)

@@ -91,6 +91,13 @@ class DitHandle:
         self._graphs = _GraphCache(lambda: lib().rald_dit_workspace_generation(self._h))
         self._reserved = 0
         self._sched = None
+        # Two-stream schedule of an NFE between 128 and 255 samples: which of the two bit-identical schedules is faster depends on the box
+        # (clocks under MFMA load differ by ~6 % across the pool; two interleaved half-batches measured +2.5 % on slower boxes and -1.5 % on the
+        # fastest).  Opt-in: with autotune_two_stream = True the first NFE of such a batch times both (eight NFEs each way, once per handle
+        # and batch size) and keeps the winner; off by default - the library's fixed threshold (256) then decides, and a profile of the process
+        # shows one schedule only.  An explicit set_two_stream_min_batch() also turns it off.
+        self.autotune_two_stream = False
+        self._two_stream_tuned = {}
 
     def __del__(self):
         try:
@@ -148,17 +155,52 @@ class DitHandle:
             raise RuntimeError(f"condition cache of {cache.numel()} bytes does not belong to a batch of {x.shape[0]} "
                                f"(expected {lib().rald_dit_cond_cache_bytes(self._h, x.shape[0])} bytes): encode the condition for the same batch")
         out = torch.empty_like(x)
-        check(lib().rald_dit_denoise(self._h, C.c_void_p(_ptr(x)), x.shape[0], sigma_row, int(per_sample),
+        B = x.shape[0]
+        if self.autotune_two_stream and 128 <= B < 256 and B not in self._two_stream_tuned and not torch.cuda.is_current_stream_capturing():
+            self._tune_two_stream(x, cache, sigma_row, per_sample, raw_F, out)
+        check(lib().rald_dit_denoise(self._h, C.c_void_p(_ptr(x)), B, sigma_row, int(per_sample),
                                      C.c_void_p(_ptr(cache)), C.c_void_p(_ptr(out)), int(raw_F), C.c_void_p(_stream())))
         return out
 
-    def set_two_stream_min_batch(self, min_batch: int) -> None:
-        """From `min_batch` samples up an NFE runs as two half-batches on two HIP streams (default 256; 0 = never)."""
+    def _tune_two_stream(self, x, cache, sigma_row, per_sample, raw_F, out) -> None:
+        """Times the whole-batch and the two-half-batch schedule of this NFE (same inputs, same bits out) and sets the library's threshold."""
+        B = x.shape[0]
+        prev = lib().rald_dit_two_stream_min_batch(self._h)
+
+        def run(n):
+            for _ in range(n):
+                check(lib().rald_dit_denoise(self._h, C.c_void_p(_ptr(x)), B, sigma_row, int(per_sample), C.c_void_p(_ptr(cache)),
+                                             C.c_void_p(_ptr(out)), int(raw_F), C.c_void_p(_stream())))
+        ms = {}
+        for mode, mb in (("whole", 0), ("split", B)):
+            self._set_two_stream(mb)
+            run(2)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run(6)
+            e1.record()
+            e1.synchronize()
+            ms[mode] = e0.elapsed_time(e1)
+        split = ms["split"] < 0.995 * ms["whole"]
+        self._two_stream_tuned[B] = (split, ms["whole"] / 6, ms["split"] / 6)
+        self._set_two_stream(min(prev if prev > 0 else 256, B) if split else max(prev, B + 1))
+
+    def _set_two_stream(self, min_batch: int) -> None:
         self._graphs.clear()                           # the workspace is re-planned
         check(lib().rald_dit_set_two_stream_min_batch(self._h, int(min_batch)))
 
+    def set_two_stream_min_batch(self, min_batch: int) -> None:
+        """From `min_batch` samples up an NFE runs as two half-batches on two HIP streams (default 256; 0 = never).  Setting it by hand
+        switches the per-box choice for batches of 128-255 (see __init__) off."""
+        self.autotune_two_stream = False
+        self._set_two_stream(min_batch)
+
     def profile_begin(self) -> None:
         check(lib().rald_dit_profile_begin(self._h))
+
+    def profile_set_kinds(self, mask: int) -> None:
+        """Which kinds (bit k, see profile_end_kinds) are bracketed from now on; profile_begin resets to all four."""
+        check(lib().rald_dit_profile_set_kinds(self._h, int(mask)))
 
     def profile_end(self):
         ms, n = C.c_double(0), C.c_int32(0)

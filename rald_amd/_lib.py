@@ -58,6 +58,7 @@ SIGNATURES = {
     "rald_dit_profile_begin": (c_int, [c_void_p]),
     "rald_dit_profile_end": (c_int, [c_void_p, C.POINTER(C.c_double), C.POINTER(c_int)]),
     "rald_dit_profile_end_kinds": (c_int, [c_void_p, C.POINTER(C.c_double), C.POINTER(c_int)]),
+    "rald_dit_profile_set_kinds": (c_int, [c_void_p, C.c_uint32]),
     "rald_ae_create": (c_int, [C.POINTER(AeConfig), C.POINTER(c_void_p)]),
     "rald_ae_destroy": (None, [c_void_p]),
     "rald_ae_load_weight": (c_int, [c_void_p, c_char_p, c_void_p, c_i64]),

@@ -95,7 +95,12 @@ int rald_dit_sample(rald_dit* h, const float* latents, int32_t batch, const void
     return h->impl.sample(latents, batch, cond_cache, num_steps, sigma_min, sigma_max, rho, out, (hipStream_t)stream);
 }
 
-int rald_dit_profile_begin(rald_dit* h) { RALD_CHECK(h, "null handle"); return h->impl.profile_begin(); }
+int rald_dit_profile_begin(rald_dit* h) { RALD_CHECK(h, "null handle"); h->impl.prof_mask = 0xf; return h->impl.profile_begin(); }
+int rald_dit_profile_set_kinds(rald_dit* h, uint32_t kind_mask) {
+    RALD_CHECK(h, "null handle");
+    h->impl.prof_mask = kind_mask & 0xfu;
+    return 0;
+}
 int rald_dit_profile_end(rald_dit* h, double* total_ms, int32_t* launches) {
     RALD_CHECK(h && total_ms && launches, "rald_dit_profile_end: null argument");
     int n = 0;

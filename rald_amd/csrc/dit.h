@@ -146,6 +146,8 @@ struct Dit {
     // weights when folded), 3 = FF2 + residual + AdaLN (K = 2048)
     static constexpr int PROF_KINDS = 4;
     bool prof_on = false;
+    unsigned prof_mask = 0xf;          // bit k: launches of kind k are bracketed while prof_on (an event pair costs ~2.5 us of stream time: 96 pairs per NFE
+                                       // were 0.5 ms of a 22 ms NFE - a caller that wants the whole-job rate beside the dominant kernel's time narrows the mask)
     std::vector<hipEvent_t> prof_ev;
     std::vector<int> prof_kind;
     int prof_used = 0;

@@ -558,7 +558,7 @@ int Dit::denoise_range(const float* x, int Bfull, int b0, int B, int sigma_row, 
 
     // live timing (rald_dit_profile_begin / _end): events around the launches of one kind on the launch stream
     auto timed_launch = [&](int kind, auto&& launch) -> int {
-        const bool timed = timed_ok && prof_on && prof_used + 2 <= (int)prof_ev.size();
+        const bool timed = timed_ok && prof_on && ((prof_mask >> kind) & 1u) && prof_used + 2 <= (int)prof_ev.size();
         if (timed) RALD_HIP(hipEventRecord(prof_ev[prof_used], st));
         RALD_TRY(launch());
         if (timed) { RALD_HIP(hipEventRecord(prof_ev[prof_used + 1], st)); prof_kind[prof_used / 2] = kind; prof_used += 2; }

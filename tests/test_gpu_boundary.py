@@ -179,3 +179,24 @@ def test_results_do_not_depend_on_what_the_lds_held_before():
         torch.cuda.synchronize()
         assert torch.isfinite(out).all(), name
         assert torch.equal(out, ref), name
+
+
+def test_two_stream_autotune_keeps_results_and_reports_its_choice():
+    """Opt-in per-box choice between the whole-batch and the two-half-batch schedule of an NFE (128-255 samples): whatever it picks, the
+    result is the bits of the untuned call, the choice is recorded once per batch size, and the library's threshold follows it."""
+    from rald_amd import synth
+    from rald_amd._lib import lib
+    m = _transformer(2)
+    h = m._handle(512, 64)
+    B = 128
+    x, cache = synth.latents(range(B)).cuda(), h.encode_cond_tokens(synth.cond_tokens(B).cuda())
+    h.set_sigmas([0.9])
+    ref = h.denoise(x, cache, 0)
+    assert not h._two_stream_tuned and lib().rald_dit_two_stream_min_batch(h._h) == 256
+    h.autotune_two_stream = True
+    out = h.denoise(x, cache, 0)
+    assert torch.equal(out, ref)
+    split, ms_whole, ms_split = h._two_stream_tuned[B]
+    assert ms_whole > 0 and ms_split > 0
+    assert lib().rald_dit_two_stream_min_batch(h._h) == (B if split else 256)
+    assert torch.equal(h.denoise(x, cache, 0), ref) and len(h._two_stream_tuned) == 1      # tuned once
